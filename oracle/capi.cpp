@@ -244,8 +244,8 @@ uint32_t or_tree_dump(const void* t, uint32_t* out, uint32_t max_nodes) {
             uint32_t* o = out + (size_t)count * 43;
             const Node* n = it.n;
             o[0] = it.depth;
-            o[1] = n->po1;
-            o[2] = n->po2;
+            o[1] = it.depth ? n->po1 : 0;  // the root's link to its old parent is not observable
+            o[2] = it.depth ? n->po2 : 0;
             o[3] = n->total_visits;
             o[4] = n->n_in_flight;
             o[5] = n->is_terminal;
@@ -254,8 +254,8 @@ uint32_t or_tree_dump(const void* t, uint32_t* out, uint32_t max_nodes) {
             o[8] = bits(n->v1);
             o[9] = bits(n->v2);
             o[10] = bits(n->value_scale);
-            o[11] = bits(n->edge_r1);
-            o[12] = bits(n->edge_r2);
+            o[11] = bits(it.depth ? n->edge_r1 : 0.0f);
+            o[12] = bits(it.depth ? n->edge_r2 : 0.0f);
             for (int i = 0; i < 5; ++i) {
                 o[13 + i * 3] = bits(n->p1.prior[i]);
                 o[14 + i * 3] = bits(n->p1.edges[i].q);

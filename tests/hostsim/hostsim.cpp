@@ -1,0 +1,265 @@
+// TEST HARNESS -- compiles the product's device-side search logic (alpharat_amd/csrc/dev_*.h,
+// written __host__ __device__) for the CPU so its control flow, arena management and arithmetic
+// can be checked against the oracle in the GPU-less build container. It is NOT a CPU fallback:
+// nothing in alpharat_amd/ loads this file, and libalpharat_hip.so has no CPU path.
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../alpharat_amd/csrc/slot_layout.h"
+#include "../../alpharat_amd/csrc/zig_norm_tables.inc"
+
+using namespace ar;
+
+static const ZigTables g_zig = {AR_ZIG_NORM_X_INIT, AR_ZIG_NORM_F_INIT};
+
+extern "C" {
+
+struct HsCfg {
+    float c_puct, fpu_reduction, force_k, noise_epsilon, noise_concentration;
+    uint32_t coll_min, coll_max, coll_start, coll_end;
+    float coll_power;
+};
+struct HsGame {
+    uint8_t width, height;
+    uint16_t max_turns, turn;
+    uint8_t p1_x, p1_y, p2_x, p2_y, p1_mud, p2_mud;
+    float p1_score, p2_score;
+    const uint8_t* cost;    // [hw*4]
+    const uint8_t* cheese;  // [hw]
+};
+
+struct HsRun {
+    Slot<4> slot;
+    std::vector<unsigned char> scratch;
+    std::vector<NodeStats> stats;
+    std::vector<NodeKids> kids;
+    std::vector<uint8_t> cost;
+    SearchCfg cfg;
+    uint32_t grows = 0;
+};
+
+static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
+    SearchCfg s;
+    s.c_puct = c->c_puct;
+    s.fpu_reduction = c->fpu_reduction;
+    s.force_k = c->force_k;
+    s.noise_epsilon = c->noise_epsilon;
+    s.noise_concentration = c->noise_concentration;
+    s.coll_min = c->coll_min;
+    s.coll_max = c->coll_max;
+    s.coll_start = c->coll_start;
+    s.coll_end = c->coll_end;
+    s.coll_power = c->coll_power;
+    s.n_sims = n_sims;
+    s.batch_size = batch;
+    return s;
+}
+
+static void grow(HsRun* r) {
+    uint32_t want = r->slot.need_nodes;
+    uint32_t ncap = r->slot.cap * 2;
+    while (ncap < want) ncap *= 2;
+    std::vector<NodeStats> ns(ncap);
+    std::vector<NodeKids> nk(ncap);
+    migrate_slot(r->slot, ns.data(), nk.data(), ncap);
+    r->stats.swap(ns);
+    r->kids.swap(nk);
+    r->slot.stats = r->stats.data();
+    r->slot.kids = r->kids.data();
+    r->grows += 1;
+}
+
+// eval_mode 0: SmartUniform inline; 1: leaves stored, harness evaluates (uniform priors + constant
+// values v1/v2) -- exercises the split gather / evaluate / backup path.
+void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, uint64_t seed, int single,
+             int eval_mode, float v1, float v2, uint32_t arena_nodes) {
+    HsRun* r = new HsRun();
+    r->cfg = to_cfg(c, n_sims, batch);
+    const int hw = g->width * g->height;
+    r->cost.assign(g->cost, g->cost + hw * 4);
+    SlotLayout L = make_layout<4>(r->cfg, g->max_turns);
+    r->scratch.assign(L.total, 0);
+    uint32_t cap = arena_nodes ? arena_nodes : initial_arena_nodes(r->cfg);
+    r->stats.resize(cap);
+    r->kids.resize(cap);
+    Slot<4>& s = r->slot;
+    std::memset(&s, 0, sizeof s);
+    bind_scratch(s, r->scratch.data(), L);
+    s.stats = r->stats.data();
+    s.kids = r->kids.data();
+    s.cap = cap;
+    s.board.width = g->width;
+    s.board.height = g->height;
+    s.board.max_turns = g->max_turns;
+    s.board.maze_off = 0;
+    uint16_t rem = 0;
+    for (int k = 0; k < 4; ++k) s.st.cheese[k] = 0;
+    for (int i = 0; i < hw; ++i)
+        if (g->cheese[i]) {
+            s.st.cheese[i >> 6] |= 1ULL << (i & 63);
+            ++rem;
+        }
+    s.st.remaining = rem;
+    s.st.s1 = g->p1_score;
+    s.st.s2 = g->p2_score;
+    s.board.total_cheese = (uint16_t)(g->p1_score + g->p2_score + (float)rem);
+    s.st.turn = g->turn;
+    s.st.p1 = (uint8_t)(g->p1_y * g->width + g->p1_x);
+    s.st.p2 = (uint8_t)(g->p2_y * g->width + g->p2_x);
+    s.st.m1 = g->p1_mud;
+    s.st.m2 = g->p2_mud;
+    rng_seed(s.rng, seed);
+    s.single_search = single;
+    const uint8_t* cost = r->cost.data();
+    start_game(s, cost, r->cfg);
+    GatherCtx cx;
+    cx.cost = cost;
+    cx.eval_mode = eval_mode == 0 ? EVAL_UNIFORM : EVAL_STORE;
+    std::vector<EvalOut> ev(batch);
+    while (s.status == SLOT_ACTIVE || s.status == SLOT_STALL) {
+        if (s.status == SLOT_STALL) {
+            grow(r);
+            continue;
+        }
+        if (!gather_batch(s, cx, r->cfg)) continue;
+        const EvalOut* evp = s.ev_local;
+        if (eval_mode != 0) {
+            for (uint32_t j = 0; j < s.b_nn; ++j) {
+                const State<4>& lf = s.leaf_local[j];
+                uniform_prior(eff_actions(cost, lf.p1, lf.m1), ev[j].p1);
+                uniform_prior(eff_actions(cost, lf.p2, lf.m2), ev[j].p2);
+                ev[j].v1 = v1;
+                ev[j].v2 = v2;
+            }
+            evp = ev.data();
+        }
+        if (backup_batch(s, r->cfg, evp, &g_zig)) finish_move(s, cost, r->cfg);
+    }
+    return r;
+}
+void hs_free(void* p) { delete (HsRun*)p; }
+
+// header: [n_positions, status, error, grows, node_count, result-unused...]
+void hs_header(const void* p, uint64_t out[12], float fs[2]) {
+    const HsRun* r = (const HsRun*)p;
+    const Slot<4>& s = r->slot;
+    out[0] = s.n_pos;
+    out[1] = s.status;
+    out[2] = s.error;
+    out[3] = r->grows;
+    out[4] = s.node_count;
+    out[5] = s.t_sims;
+    out[6] = s.t_nn;
+    out[7] = s.t_term;
+    out[8] = s.t_coll;
+    out[9] = s.nv_gather;
+    out[10] = s.nv_backup;
+    out[11] = s.new_nodes;
+    fs[0] = s.st.s1;
+    fs[1] = s.st.s2;
+}
+// final position: [p1x,p1y,p2x,p2y,turn,remaining], final cheese mask
+void hs_final(const void* p, int32_t out[6], uint8_t* mask) {
+    const HsRun* r = (const HsRun*)p;
+    const Slot<4>& s = r->slot;
+    int w = s.board.width;
+    out[0] = s.st.p1 % w;
+    out[1] = s.st.p1 / w;
+    out[2] = s.st.p2 % w;
+    out[3] = s.st.p2 / w;
+    out[4] = s.st.turn;
+    out[5] = s.st.remaining;
+    for (int i = 0; i < s.board.width * s.board.height; ++i) mask[i] = st_has_cheese(s.st, i);
+}
+static void fill_floats(const MoveResult& m, float* F) {
+    F[2] = m.value[0];
+    F[3] = m.value[1];
+    std::memcpy(F + 4, m.visit_counts[0], 20);
+    std::memcpy(F + 9, m.visit_counts[1], 20);
+    std::memcpy(F + 14, m.prior[0], 20);
+    std::memcpy(F + 19, m.prior[1], 20);
+    std::memcpy(F + 24, m.policy[0], 20);
+    std::memcpy(F + 29, m.policy[1], 20);
+}
+// same per-position layout as the oracle driver (tests/_oracle.py play_game)
+void hs_positions(const void* p, int32_t* ints, float* floats, uint8_t* masks) {
+    const HsRun* r = (const HsRun*)p;
+    const Slot<4>& s = r->slot;
+    int w = s.board.width, hw = s.board.width * s.board.height;
+    for (uint32_t i = 0; i < s.n_pos; ++i) {
+        const PosRec<4>& q = s.pos[i];
+        int32_t* I = ints + (size_t)i * 9;
+        I[0] = q.st.p1 % w;
+        I[1] = q.st.p1 / w;
+        I[2] = q.st.p2 % w;
+        I[3] = q.st.p2 / w;
+        I[4] = q.st.m1;
+        I[5] = q.st.m2;
+        I[6] = q.st.turn;
+        I[7] = q.a1;
+        I[8] = q.a2;
+        float* F = floats + (size_t)i * 34;
+        F[0] = q.st.s1;
+        F[1] = q.st.s2;
+        fill_floats(q.res, F);
+        for (int c = 0; c < hw; ++c) masks[(size_t)i * hw + c] = st_has_cheese(q.st, c);
+    }
+}
+// last search result (single-search mode): floats as positions' F[2..34), counters
+void hs_last(const void* p, float* F34, uint32_t cnt[4]) {
+    const HsRun* r = (const HsRun*)p;
+    const MoveResult& m = r->slot.last;
+    F34[0] = F34[1] = 0;
+    fill_floats(m, F34);
+    cnt[0] = m.total_visits;
+    cnt[1] = m.nn_evals;
+    cnt[2] = m.terminals;
+    cnt[3] = m.collisions;
+}
+// canonical tree dump, same 43-word rows as the oracle's or_tree_dump
+uint32_t hs_tree_dump(const void* p, uint32_t* out, uint32_t max_nodes) {
+    const HsRun* r = (const HsRun*)p;
+    const Slot<4>& s = r->slot;
+    struct It {
+        uint32_t id, depth;
+    };
+    std::vector<It> st{{s.root, 0}};
+    uint32_t count = 0;
+    while (!st.empty()) {
+        It it = st.back();
+        st.pop_back();
+        const NodeStats& n = s.stats[it.id];
+        if (count < max_nodes) {
+            uint32_t* o = out + (size_t)count * 43;
+            o[0] = it.depth;
+            o[1] = it.depth ? n.po[0] : 0;
+            o[2] = it.depth ? n.po[1] : 0;
+            o[3] = n.visits;
+            o[4] = n.nif;
+            o[5] = n.terminal;
+            o[6] = n.n[0];
+            o[7] = n.n[1];
+            o[8] = f32_to_bits(n.v1);
+            o[9] = f32_to_bits(n.v2);
+            o[10] = f32_to_bits(n.scale);
+            o[11] = f32_to_bits(it.depth ? n.r1 : 0.0f);
+            o[12] = f32_to_bits(it.depth ? n.r2 : 0.0f);
+            for (int i = 0; i < 5; ++i) {
+                o[13 + i * 3] = f32_to_bits(n.e[0][i].prior);
+                o[14 + i * 3] = f32_to_bits(n.e[0][i].q);
+                o[15 + i * 3] = n.e[0][i].visits;
+                o[28 + i * 3] = f32_to_bits(n.e[1][i].prior);
+                o[29 + i * 3] = f32_to_bits(n.e[1][i].q);
+                o[30 + i * 3] = n.e[1][i].visits;
+            }
+        }
+        ++count;
+        for (int i = 24; i >= 0; --i)
+            if (s.kids[it.id].c[i] != NIL) st.push_back({s.kids[it.id].c[i], it.depth + 1});
+    }
+    return count;
+}
+
+}  // extern "C"
