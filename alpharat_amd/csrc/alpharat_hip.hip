@@ -1,0 +1,1245 @@
+// libalpharat_hip.so -- HIP kernels + host runtime + C-ABI (include/alpharat_hip.h).
+//
+// Host runtime = the MI355X counterpart of crates/alpharat-sampling/src/selfplay.rs:609-808
+// (game_worker_loop / run_self_play_to_disk): instead of N OS threads each walking one tree,
+// every resident game advances one simulate_batch per kernel step; finished games are drained to
+// a writer thread and their slots refilled from the pending game list.
+//
+// gfx950 only. No CPU path: every entry point needs a HIP device and fails with AR_E_DEVICE
+// without one.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/alpharat_hip.h"
+#include "nets.h"
+#include "npz_writer.h"
+#include "slot_layout.h"
+#include "zig_norm_tables.inc"
+
+using namespace ar;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+static int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+static int nets_fail(int code, const std::string& msg) { return fail(code, msg); }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(AR_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));           \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+struct GameInit {
+    Board board;
+    State<NW> st;
+    uint64_t rng_seed;
+    uint32_t game_index;
+    uint32_t slot;
+    uint32_t single;
+    uint32_t pad;
+};
+
+template <int NW>
+struct DoneInfo {
+    uint32_t slot, game_index, n_pos, error;
+    State<NW> final_st;
+    uint64_t t_sims, t_nn, t_term, t_coll, nv_gather, nv_backup, new_nodes;
+    MoveResult last;
+};
+
+struct ArenaPool {
+    NodeStats* stats;
+    NodeKids* kids;
+    uint32_t cap0;
+};
+
+template <int NW>
+__global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, unsigned char* scratch,
+                             SlotLayout L, ArenaPool pool, const uint8_t* maze_pool, SearchCfg cfg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const GameInit<NW>& gi = init[i];
+    Slot<NW>& s = slots[gi.slot];
+    if (s.stats == nullptr) {
+        s.stats = pool.stats + (size_t)gi.slot * pool.cap0;
+        s.kids = pool.kids + (size_t)gi.slot * pool.cap0;
+        s.cap = pool.cap0;
+    }
+    bind_scratch(s, scratch + (size_t)gi.slot * L.total, L);
+    s.board = gi.board;
+    s.st = gi.st;
+    rng_seed(s.rng, gi.rng_seed);
+    s.game_index = gi.game_index;
+    s.single_search = gi.single;
+    start_game(s, maze_pool + gi.board.maze_off, cfg);
+}
+
+// One thread walks one game's tree: `iters` x (gather -> evaluate -> backup [-> end of turn]).
+// SmartUniform is evaluated inside the gather, so the whole simulate_batch is one pass.
+template <int NW>
+__global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
+                                                     const uint8_t* maze_pool, const ZigTables* zt, int iters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    Slot<NW>& s = slots[i];
+    GatherCtx cx;
+    cx.cost = maze_pool + s.board.maze_off;
+    cx.eval_mode = EVAL_UNIFORM;
+    for (int it = 0; it < iters; ++it) {
+        if (s.status != SLOT_ACTIVE) break;
+        if (!gather_batch(s, cx, cfg)) break;
+        if (backup_batch(s, cfg, s.ev_local, zt)) finish_move(s, cx.cost, cfg);
+    }
+}
+
+// Split form for evaluators that run outside the tree walk (networks, host callbacks).
+template <int NW>
+__global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
+                                               const uint8_t* maze_pool, LeafReq<NW>* queue, uint32_t* queue_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    Slot<NW>& s = slots[i];
+    if (s.status != SLOT_ACTIVE) return;
+    GatherCtx cx;
+    cx.cost = maze_pool + s.board.maze_off;
+    cx.eval_mode = EVAL_STORE;
+    if (!gather_batch(s, cx, cfg)) return;
+    if (queue != nullptr && s.b_nn > 0) {
+        const uint32_t base = atomicAdd(queue_count, s.b_nn);
+        s.eval_base = base;
+        for (uint32_t j = 0; j < s.b_nn; ++j) {
+            queue[base + j].st = s.leaf_local[j];
+            queue[base + j].slot = i;
+            queue[base + j].pad = 0;
+        }
+    }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
+                                               const uint8_t* maze_pool, const ZigTables* zt, const EvalOut* ev_queue) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    Slot<NW>& s = slots[i];
+    if (s.status != SLOT_ACTIVE || !s.batch_active) return;
+    const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : s.ev_local;
+    if (backup_batch(s, cfg, ev, zt)) finish_move(s, maze_pool + s.board.maze_off, cfg);
+}
+
+// evaluator failure: revert the gathered batch (search.rs:919-955)
+template <int NW>
+__global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    Slot<NW>& s = slots[i];
+    if (s.batch_active) cancel_batch(s);
+    if (s.status == SLOT_ACTIVE) s.status = SLOT_FAILED;
+}
+
+// counts[0] done, [1] stalled, [2] active, [3] errors; lists hold slot ids
+template <int NW>
+__global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts, uint32_t* done_list,
+                       uint32_t* stall_list) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const Slot<NW>& s = slots[i];
+    if (s.error) atomicAdd(&counts[3], 1u);
+    if (s.status == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
+    else if (s.status == SLOT_STALL) stall_list[atomicAdd(&counts[1], 1u)] = i;
+    else if (s.status == SLOT_ACTIVE) atomicAdd(&counts[2], 1u);
+}
+
+// one block per finished game: header by thread 0, position records copied by the whole block
+template <int NW>
+__global__ void k_pack_done(Slot<NW>* slots, const uint32_t* done_list, uint32_t n_done, DoneInfo<NW>* info,
+                            PosRec<NW>* staging, uint32_t max_turns) {
+    const uint32_t d = blockIdx.x;
+    if (d >= n_done) return;
+    Slot<NW>& s = slots[done_list[d]];
+    if (threadIdx.x == 0) {
+        DoneInfo<NW>& o = info[d];
+        o.slot = done_list[d];
+        o.game_index = s.game_index;
+        o.n_pos = s.n_pos;
+        o.error = s.error;
+        o.final_st = s.st;
+        o.t_sims = s.t_sims;
+        o.t_nn = s.t_nn;
+        o.t_term = s.t_term;
+        o.t_coll = s.t_coll;
+        o.nv_gather = s.nv_gather;
+        o.nv_backup = s.nv_backup;
+        o.new_nodes = s.new_nodes;
+        o.last = s.last;
+    }
+    const uint32_t n = s.n_pos < max_turns ? s.n_pos : max_turns;
+    const uint32_t words = n * (uint32_t)(sizeof(PosRec<NW>) / 4);
+    const uint32_t* src = (const uint32_t*)s.pos;
+    uint32_t* dst = (uint32_t*)(staging + (size_t)d * max_turns);
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    __syncthreads();
+    if (threadIdx.x == 0) s.status = SLOT_EMPTY;
+}
+
+struct GrowReq {
+    uint32_t slot;
+    uint32_t cap;
+    NodeStats* stats;
+    NodeKids* kids;
+};
+template <int NW>
+__global__ void k_migrate(Slot<NW>* slots, const GrowReq* req, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    migrate_slot(slots[req[i].slot], req[i].stats, req[i].kids, req[i].cap);
+}
+
+template <int NW>
+__global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, uint32_t n, uint32_t* need,
+                             uint32_t* cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    need[i] = slots[stall_list[i]].need_nodes;
+    cap[i] = slots[stall_list[i]].cap;
+}
+
+// host-callback evaluator support: leaves out, results in (single-slot searches)
+template <int NW>
+__global__ void k_export_leaves(const Slot<NW>* slots, uint32_t slot, State<NW>* out, uint32_t* n_out) {
+    const Slot<NW>& s = slots[slot];
+    if (threadIdx.x == 0) *n_out = s.batch_active ? s.b_nn : 0;
+    for (uint32_t j = threadIdx.x; j < s.b_nn; j += blockDim.x) out[j] = s.leaf_local[j];
+}
+template <int NW>
+__global__ void k_import_evals(Slot<NW>* slots, uint32_t slot, const EvalOut* in, uint32_t n) {
+    Slot<NW>& s = slots[slot];
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) s.ev_local[j] = in[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: game generation (our own seeded sampler, DESIGN.md "game generation")
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct HostRng {  // same generator family as the device stream, host copy for game generation
+    Rng r;
+    explicit HostRng(uint64_t seed) { rng_seed(r, seed); }
+    uint32_t below(uint32_t n) { return rng_below(r, n); }
+};
+
+struct HostGame {
+    uint8_t width, height;
+    uint16_t max_turns, turn;
+    uint8_t p1, p2, m1, m2;
+    float s1, s2;
+    std::vector<uint8_t> cheese;  // [hw]
+    uint16_t total_cheese;
+};
+
+// 180-degree-symmetric cheese: shuffle the pair representatives (i < N-1-i, start cells excluded)
+// with Fisher-Yates driven by gen_range, take count/2 pairs; an odd count uses the centre cell.
+bool place_cheese(HostGame& g, uint32_t count, bool symmetric, uint64_t seed, std::string& err) {
+    const int n = g.width * g.height;
+    g.cheese.assign(n, 0);
+    HostRng rng(seed);
+    std::vector<int> cand;
+    uint32_t need = count;
+    if (symmetric) {
+        int centre = -1;
+        for (int i = 0; i < n; ++i) {
+            const int j = n - 1 - i;
+            if (i == g.p1 || i == g.p2 || j == g.p1 || j == g.p2) continue;
+            if (i < j) cand.push_back(i);
+            else if (i == j) centre = i;
+        }
+        if (need & 1u) {
+            if (centre < 0) {
+                err = "odd symmetric cheese count needs a free centre cell";
+                return false;
+            }
+            g.cheese[centre] = 1;
+            need -= 1;
+        }
+        if (need / 2 > cand.size()) {
+            err = "cheese_count does not fit the board";
+            return false;
+        }
+        for (int i = (int)cand.size() - 1; i >= 1; --i) std::swap(cand[i], cand[rng.below((uint32_t)i + 1)]);
+        for (uint32_t k = 0; k < need / 2; ++k) {
+            g.cheese[cand[k]] = 1;
+            g.cheese[n - 1 - cand[k]] = 1;
+        }
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (i != g.p1 && i != g.p2) cand.push_back(i);
+        if (need > cand.size()) {
+            err = "cheese_count does not fit the board";
+            return false;
+        }
+        for (int i = (int)cand.size() - 1; i >= 1; --i) std::swap(cand[i], cand[rng.below((uint32_t)i + 1)]);
+        for (uint32_t k = 0; k < need; ++k) g.cheese[cand[k]] = 1;
+    }
+    g.total_cheese = (uint16_t)count;
+    return true;
+}
+
+std::vector<uint8_t> open_maze_cost(int w, int h) {
+    std::vector<uint8_t> c((size_t)w * h * 4, 0);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint8_t* p = &c[((size_t)y * w + x) * 4];
+            p[DIR_UP] = y + 1 < h;
+            p[DIR_RIGHT] = x + 1 < w;
+            p[DIR_DOWN] = y > 0;
+            p[DIR_LEFT] = x > 0;
+        }
+    return c;
+}
+
+template <int NW>
+void fill_state(const HostGame& g, Board& b, State<NW>& st, uint32_t maze_off) {
+    b.width = g.width;
+    b.height = g.height;
+    b.max_turns = g.max_turns;
+    b.total_cheese = g.total_cheese;
+    b.maze_off = maze_off;
+    for (int k = 0; k < NW; ++k) st.cheese[k] = 0;
+    uint16_t rem = 0;
+    for (size_t i = 0; i < g.cheese.size(); ++i)
+        if (g.cheese[i]) {
+            st.cheese[NW == 1 ? 0 : (i >> 6)] |= 1ULL << (i & 63);
+            ++rem;
+        }
+    st.remaining = rem;
+    st.s1 = g.s1;
+    st.s2 = g.s2;
+    st.turn = g.turn;
+    st.p1 = g.p1;
+    st.p2 = g.p2;
+    st.m1 = g.m1;
+    st.m2 = g.m2;
+}
+
+SearchCfg to_cfg(const ArSearchConfig& c, uint32_t sims, uint32_t batch) {
+    SearchCfg s;
+    s.c_puct = c.c_puct;
+    s.fpu_reduction = c.fpu_reduction;
+    s.force_k = c.force_k;
+    s.noise_epsilon = c.noise_epsilon;
+    s.noise_concentration = c.noise_concentration;
+    s.coll_min = c.collision_limit_min;
+    s.coll_max = c.collision_limit_max;
+    s.coll_start = c.collision_scaling_start;
+    s.coll_end = c.collision_scaling_end;
+    s.coll_power = c.collision_scaling_power;
+    s.n_sims = sims;
+    s.batch_size = batch;
+    return s;
+}
+
+int check_cfg(const SearchCfg& c) {
+    if (c.n_sims == 0) return fail(AR_E_INVALID, "simulations must be > 0");
+    if (c.batch_size == 0 || c.batch_size > 4096) return fail(AR_E_INVALID, "batch_size must be in 1..4096");
+    if (c.coll_max > 65536) return fail(AR_E_INVALID, "collision_limit_max must be <= 65536");
+    if (c.noise_epsilon > 0.0f && !(c.noise_concentration / 5.0f > 1.0f))
+        return fail(AR_E_INVALID, "noise_concentration must exceed 5 (Gamma shape >= 1 path only)");
+    return AR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: the engine -- device-resident slots and the step loop
+// ------------------------------------------------------------------------------------------------
+struct GameRecordHost {  // owning twin of ArGameRecordView
+    uint8_t width, height;
+    uint16_t max_turns;
+    uint32_t game_index, n;
+    std::vector<int8_t> maze;
+    std::vector<uint8_t> initial_cheese, cheese_outcomes;
+    float final_p1, final_p2;
+    uint8_t result;
+    uint16_t cheese_available;
+    uint64_t sims, nn, term, coll;
+    std::vector<uint8_t> p1_pos, p2_pos, p1_mud, p2_mud, cheese_mask, a1, a2;
+    std::vector<float> p1_score, p2_score, v1, v2, vc1, vc2, pr1, pr2, po1, po2;
+    std::vector<uint16_t> turn;
+    ArGameRecordView view() const {
+        ArGameRecordView v;
+        memset(&v, 0, sizeof v);
+        v.width = width;
+        v.height = height;
+        v.max_turns = max_turns;
+        v.game_index = game_index;
+        v.n_positions = n;
+        v.maze = maze.data();
+        v.initial_cheese = initial_cheese.data();
+        v.cheese_outcomes = cheese_outcomes.data();
+        v.final_p1_score = final_p1;
+        v.final_p2_score = final_p2;
+        v.result = result;
+        v.cheese_available = cheese_available;
+        v.total_simulations = sims;
+        v.total_nn_evals = nn;
+        v.total_terminals = term;
+        v.total_collisions = coll;
+        v.p1_pos = p1_pos.data();
+        v.p2_pos = p2_pos.data();
+        v.p1_score = p1_score.data();
+        v.p2_score = p2_score.data();
+        v.p1_mud = p1_mud.data();
+        v.p2_mud = p2_mud.data();
+        v.turn = turn.data();
+        v.cheese_mask = cheese_mask.data();
+        v.value_p1 = v1.data();
+        v.value_p2 = v2.data();
+        v.visit_counts_p1 = vc1.data();
+        v.visit_counts_p2 = vc2.data();
+        v.prior_p1 = pr1.data();
+        v.prior_p2 = pr2.data();
+        v.policy_p1 = po1.data();
+        v.policy_p2 = po2.data();
+        v.action_p1 = a1.data();
+        v.action_p2 = a2.data();
+        return v;
+    }
+};
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void**)&p, sizeof(T) * (count ? count : 1));
+    }
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    hipError_t alloc(size_t count) { return hipHostMalloc((void**)&p, sizeof(T) * (count ? count : 1)); }
+    ~PinBuf() {
+        if (p) hipHostFree(p);
+    }
+};
+
+template <int NW>
+struct Engine {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    uint32_t S = 0;
+    SearchCfg cfg;
+    SlotLayout L;
+    uint32_t max_turns = 0, cap0 = 0;
+    DevBuf<Slot<NW>> slots;
+    DevBuf<unsigned char> scratch;
+    DevBuf<NodeStats> stats;
+    DevBuf<NodeKids> kids;
+    DevBuf<uint8_t> maze;
+    DevBuf<ZigTables> zig;
+    DevBuf<uint32_t> counts, done_list, stall_list, need, capv;
+    DevBuf<GameInit<NW>> init;
+    DevBuf<DoneInfo<NW>> info;
+    DevBuf<PosRec<NW>> staging;
+    DevBuf<GrowReq> grow;
+    DevBuf<LeafReq<NW>> queue;
+    DevBuf<EvalOut> ev_queue;
+    DevBuf<uint32_t> queue_count;
+    PinBuf<uint32_t> h_counts, h_done, h_stall, h_need, h_cap;
+    PinBuf<DoneInfo<NW>> h_info;
+    PinBuf<PosRec<NW>> h_staging;
+    std::vector<void*> grown;  // arenas allocated after a stall, freed with the engine
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double device_ms = 0.0;
+    uint64_t steps = 0;
+    uint64_t grows = 0;
+    ArNet* net = nullptr;
+
+    ~Engine() {
+        for (void* p : grown) hipFree(p);
+        if (ev0) hipEventDestroy(ev0);
+        if (ev1) hipEventDestroy(ev1);
+        if (stream) hipStreamDestroy(stream);
+    }
+
+    int setup(int device, uint32_t n_slots, const SearchCfg& c, uint32_t mt, const std::vector<uint8_t>& maze_bytes,
+              uint32_t arena_nodes, bool need_queue) {
+        dev = device;
+        S = n_slots;
+        cfg = c;
+        max_turns = mt;
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreate(&stream));
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+        L = make_layout<NW>(cfg, max_turns);
+        cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
+        HIP_TRY(slots.alloc(S));
+        HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
+        HIP_TRY(scratch.alloc((size_t)S * L.total));
+        HIP_TRY(stats.alloc((size_t)S * cap0));
+        HIP_TRY(kids.alloc((size_t)S * cap0));
+        HIP_TRY(maze.alloc(maze_bytes.size()));
+        HIP_TRY(hipMemcpyAsync(maze.p, maze_bytes.data(), maze_bytes.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(zig.alloc(1));
+        static const ZigTables host_zig = {AR_ZIG_NORM_X_INIT, AR_ZIG_NORM_F_INIT};
+        HIP_TRY(hipMemcpyAsync(zig.p, &host_zig, sizeof host_zig, hipMemcpyHostToDevice, stream));
+        HIP_TRY(counts.alloc(4));
+        HIP_TRY(done_list.alloc(S));
+        HIP_TRY(stall_list.alloc(S));
+        HIP_TRY(need.alloc(S));
+        HIP_TRY(capv.alloc(S));
+        HIP_TRY(init.alloc(S));
+        HIP_TRY(info.alloc(S));
+        HIP_TRY(staging.alloc((size_t)S * max_turns));
+        HIP_TRY(grow.alloc(S));
+        HIP_TRY(h_counts.alloc(4));
+        HIP_TRY(h_done.alloc(S));
+        HIP_TRY(h_stall.alloc(S));
+        HIP_TRY(h_need.alloc(S));
+        HIP_TRY(h_cap.alloc(S));
+        HIP_TRY(h_info.alloc(S));
+        HIP_TRY(h_staging.alloc((size_t)S * max_turns));
+        if (need_queue) {
+            HIP_TRY(queue.alloc((size_t)S * cfg.batch_size));
+            HIP_TRY(ev_queue.alloc((size_t)S * cfg.batch_size));
+            HIP_TRY(queue_count.alloc(1));
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return AR_OK;
+    }
+
+    uint32_t grid(uint32_t n) const { return (n + 63) / 64; }
+
+    int start_games(const std::vector<GameInit<NW>>& games) {
+        if (games.empty()) return AR_OK;
+        HIP_TRY(hipMemcpyAsync(init.p, games.data(), sizeof(GameInit<NW>) * games.size(), hipMemcpyHostToDevice, stream));
+        ArenaPool pool{stats.p, kids.p, cap0};
+        hipLaunchKernelGGL(k_init_games<NW>, dim3(grid((uint32_t)games.size())), dim3(64), 0, stream, slots.p, init.p,
+                           (uint32_t)games.size(), scratch.p, L, pool, maze.p, cfg);
+        HIP_TRY(hipGetLastError());
+        // init.p is reused by the next call: wait for the copy + kernel
+        HIP_TRY(hipStreamSynchronize(stream));
+        return AR_OK;
+    }
+
+    // `n_launch` kernel steps of `iters` simulate_batch each, timed with HIP events on our stream
+    int run_steps(int n_launch, int iters) {
+        HIP_TRY(hipEventRecord(ev0, stream));
+        for (int k = 0; k < n_launch; ++k) {
+            if (net == nullptr) {
+                hipLaunchKernelGGL(k_step_uniform<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p,
+                                   zig.p, iters);
+                steps += (uint64_t)iters;
+            } else {
+                for (int it = 0; it < iters; ++it) {
+                    HIP_TRY(hipMemsetAsync(queue_count.p, 0, 4, stream));
+                    hipLaunchKernelGGL(k_gather<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p,
+                                       queue.p, queue_count.p);
+                    int rc = net_forward_queue<NW>(net, queue.p, queue_count.p, (uint32_t)((size_t)S * cfg.batch_size),
+                                                   slots.p, maze.p, ev_queue.p, stream);
+                    if (rc != AR_OK) return rc;
+                    hipLaunchKernelGGL(k_backup<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p, zig.p,
+                                       ev_queue.p);
+                    steps += 1;
+                }
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1, stream));
+        return AR_OK;
+    }
+
+    // after run_steps: status lists on the host. Also accumulates device time.
+    int scan(uint32_t out_counts[4]) {
+        HIP_TRY(hipMemsetAsync(counts.p, 0, 16, stream));
+        hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
+                           stall_list.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
+        for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
+        return AR_OK;
+    }
+
+    int handle_stalls(uint32_t n_stall) {
+        if (n_stall == 0) return AR_OK;
+        hipLaunchKernelGGL(k_read_stall<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, stall_list.p, n_stall,
+                           need.p, capv.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_stall.p, stall_list.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_need.p, need.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_cap.p, capv.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<GrowReq> reqs(n_stall);
+        for (uint32_t i = 0; i < n_stall; ++i) {
+            uint32_t ncap = h_cap.p[i] * 2;
+            while (ncap < h_need.p[i]) ncap *= 2;
+            NodeStats* ns = nullptr;
+            NodeKids* nk = nullptr;
+            if (hipMalloc((void**)&ns, sizeof(NodeStats) * (size_t)ncap) != hipSuccess ||
+                hipMalloc((void**)&nk, sizeof(NodeKids) * (size_t)ncap) != hipSuccess)
+                return fail(AR_E_NOMEM, "out of device memory while growing a tree arena to " + std::to_string(ncap) +
+                                            " nodes");
+            grown.push_back(ns);
+            grown.push_back(nk);
+            reqs[i] = GrowReq{h_stall.p[i], ncap, ns, nk};
+        }
+        HIP_TRY(hipMemcpyAsync(grow.p, reqs.data(), sizeof(GrowReq) * n_stall, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_migrate<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+        grows += n_stall;
+        return AR_OK;
+    }
+
+    // copies the finished games' headers + positions to pinned host memory and frees their slots
+    int drain(uint32_t n_done) {
+        if (n_done == 0) return AR_OK;
+        hipLaunchKernelGGL(k_pack_done<NW>, dim3(n_done), dim3(128), 0, stream, slots.p, done_list.p, n_done, info.p,
+                           staging.p, max_turns);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_info.p, info.p, sizeof(DoneInfo<NW>) * n_done, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_staging.p, staging.p, sizeof(PosRec<NW>) * (size_t)n_done * max_turns,
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return AR_OK;
+    }
+};
+
+// maze[y][x][dir] as the recorder stores it (selfplay.rs:374-392)
+std::vector<int8_t> maze_array(const std::vector<uint8_t>& cost) {
+    std::vector<int8_t> m(cost.size());
+    for (size_t i = 0; i < cost.size(); ++i) m[i] = cost[i] ? (int8_t)cost[i] : (int8_t)-1;
+    return m;
+}
+
+template <int NW>
+void record_from_device(const DoneInfo<NW>& d, const PosRec<NW>* pos, const HostGame& g0,
+                        const std::vector<uint8_t>& cost, GameRecordHost& r) {
+    const int w = g0.width, hw = g0.width * g0.height;
+    r.width = g0.width;
+    r.height = g0.height;
+    r.max_turns = g0.max_turns;
+    r.game_index = d.game_index;
+    r.n = d.n_pos;
+    r.maze = maze_array(cost);
+    r.initial_cheese = g0.cheese;
+    r.cheese_available = g0.total_cheese;
+    r.final_p1 = d.final_st.s1;
+    r.final_p2 = d.final_st.s2;
+    r.result = r.final_p1 > r.final_p2 ? 1 : r.final_p2 > r.final_p1 ? 2 : 0;
+    r.sims = d.t_sims;
+    r.nn = d.t_nn;
+    r.term = d.t_term;
+    r.coll = d.t_coll;
+    const size_t n = r.n;
+    r.p1_pos.resize(n * 2);
+    r.p2_pos.resize(n * 2);
+    r.p1_mud.resize(n);
+    r.p2_mud.resize(n);
+    r.cheese_mask.resize(n * hw);
+    r.a1.resize(n);
+    r.a2.resize(n);
+    r.p1_score.resize(n);
+    r.p2_score.resize(n);
+    r.v1.resize(n);
+    r.v2.resize(n);
+    r.vc1.resize(n * 5);
+    r.vc2.resize(n * 5);
+    r.pr1.resize(n * 5);
+    r.pr2.resize(n * 5);
+    r.po1.resize(n * 5);
+    r.po2.resize(n * 5);
+    r.turn.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const PosRec<NW>& p = pos[i];
+        r.p1_pos[i * 2] = p.st.p1 % w;
+        r.p1_pos[i * 2 + 1] = p.st.p1 / w;
+        r.p2_pos[i * 2] = p.st.p2 % w;
+        r.p2_pos[i * 2 + 1] = p.st.p2 / w;
+        r.p1_mud[i] = p.st.m1;
+        r.p2_mud[i] = p.st.m2;
+        r.turn[i] = p.st.turn;
+        r.p1_score[i] = p.st.s1;
+        r.p2_score[i] = p.st.s2;
+        for (int c = 0; c < hw; ++c) r.cheese_mask[i * hw + c] = st_has_cheese(p.st, c) ? 1 : 0;
+        r.v1[i] = p.res.value[0];
+        r.v2[i] = p.res.value[1];
+        memcpy(&r.vc1[i * 5], p.res.visit_counts[0], 20);
+        memcpy(&r.vc2[i * 5], p.res.visit_counts[1], 20);
+        memcpy(&r.pr1[i * 5], p.res.prior[0], 20);
+        memcpy(&r.pr2[i * 5], p.res.prior[1], 20);
+        memcpy(&r.po1[i * 5], p.res.policy[0], 20);
+        memcpy(&r.po2[i * 5], p.res.policy[1], 20);
+        r.a1[i] = p.a1;
+        r.a2[i] = p.a2;
+    }
+    // selfplay.rs:415-471 compute_cheese_outcomes: diff consecutive masks against the next positions
+    r.cheese_outcomes.assign(hw, 2);
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* cur = &r.cheese_mask[i * hw];
+        uint8_t n1, n2;
+        std::vector<uint8_t> last_mask;
+        const uint8_t* next;
+        if (i + 1 < n) {
+            next = &r.cheese_mask[(i + 1) * hw];
+            n1 = pos[i + 1].st.p1;
+            n2 = pos[i + 1].st.p2;
+        } else {
+            last_mask.resize(hw);
+            for (int c = 0; c < hw; ++c) last_mask[c] = st_has_cheese(d.final_st, c) ? 1 : 0;
+            next = last_mask.data();
+            n1 = d.final_st.p1;
+            n2 = d.final_st.p2;
+        }
+        for (int c = 0; c < hw; ++c)
+            if (cur[c] == 1 && next[c] == 0) r.cheese_outcomes[c] = (n1 == c && n2 == c) ? 1 : n1 == c ? 0 : n2 == c ? 3 : 2;
+    }
+}
+
+std::string uuid4() {
+    static std::mutex m;
+    static std::mt19937_64 gen{std::random_device{}()};
+    std::lock_guard<std::mutex> lk(m);
+    uint64_t a = gen(), b = gen();
+    a = (a & 0xFFFFFFFFFFFF0FFFULL) | 0x0000000000004000ULL;
+    b = (b & 0x3FFFFFFFFFFFFFFFULL) | 0x8000000000000000ULL;
+    char buf[40];
+    snprintf(buf, sizeof buf, "%08x-%04x-%04x-%04x-%012llx", (uint32_t)(a >> 32), (uint32_t)((a >> 16) & 0xFFFF),
+             (uint32_t)(a & 0xFFFF), (uint32_t)(b >> 48), (unsigned long long)(b & 0xFFFFFFFFFFFFULL));
+    return buf;
+}
+
+// writer thread: recording.rs:170-224 BundleWriter behind an unbounded queue (selfplay.rs:742-757)
+struct BundleSink {
+    std::string dir;
+    uint32_t max_games = 32;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<GameRecordHost>> q;
+    bool closed = false;
+    std::string error;
+    std::thread th;
+    std::vector<std::shared_ptr<GameRecordHost>> buf;
+    std::vector<std::string> paths;
+
+    void start() {
+        th = std::thread([this]() {
+            for (;;) {
+                std::shared_ptr<GameRecordHost> g;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [this] { return closed || !q.empty(); });
+                    if (q.empty()) break;
+                    g = q.front();
+                    q.pop_front();
+                }
+                buf.push_back(g);
+                if (buf.size() >= max_games) flush();
+            }
+            flush();
+        });
+    }
+    void flush() {
+        if (buf.empty() || !error.empty()) {
+            buf.clear();
+            return;
+        }
+        std::vector<ArGameRecordView> views;
+        for (auto& g : buf) views.push_back(g->view());
+        std::string path = dir + "/bundle_" + uuid4() + ".npz", err;
+        if (!write_bundle(views.data(), (uint32_t)views.size(), path, err)) error = err;
+        else paths.push_back(path);
+        buf.clear();
+    }
+    void push(std::shared_ptr<GameRecordHost> g) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(std::move(g));
+        }
+        cv.notify_one();
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            closed = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
+
+int parse_device(const char* device, int device_index, int& out) {
+    std::string d = device ? device : "auto";
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(AR_E_DEVICE, "no HIP device visible: libalpharat_hip has no CPU path");
+    if (d == "auto" || d == "hip" || d == "mi355x" || d == "cuda" || d == "rocm") out = device_index;
+    else if (d.rfind("hip:", 0) == 0) out = atoi(d.c_str() + 4);
+    else return fail(AR_E_INVALID, "device '" + d + "' is not available in the HIP sampler (use auto | hip | hip:N)");
+    if (out < 0 || out >= n) return fail(AR_E_INVALID, "device index " + std::to_string(out) + " out of range");
+    return AR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-play driver
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress* progress, ArGameSink sink,
+                  void* sink_user, ArSelfPlayStats* out) {
+    SearchCfg cfg = to_cfg(p.search, p.simulations, p.batch_size);
+    if (int rc = check_cfg(cfg)) return rc;
+    const std::vector<uint8_t> cost = open_maze_cost(p.width, p.height);
+    const int hw = p.width * p.height;
+
+    uint64_t gseed = p.game_seed_base, rseed = p.rng_seed_base;
+    if (!p.has_seed) {  // reference behaviour: entropy (selfplay.rs:622, bindings.rs:530-532)
+        std::random_device rd;
+        gseed = ((uint64_t)rd() << 32) | rd();
+        rseed = ((uint64_t)rd() << 32) | rd();
+    }
+    const bool random_pos = p.positions && std::string(p.positions) == "random";
+
+    auto make_game = [&](uint32_t index, HostGame& g, std::string& err) -> bool {
+        g.width = p.width;
+        g.height = p.height;
+        g.max_turns = p.max_turns;
+        g.turn = 0;
+        g.m1 = g.m2 = 0;
+        g.s1 = g.s2 = 0.0f;
+        g.p1 = 0;
+        g.p2 = (uint8_t)(hw - 1);
+        if (random_pos) {
+            HostRng rng((gseed + index) ^ 0x9E3779B97F4A7C15ULL);
+            g.p1 = (uint8_t)rng.below((uint32_t)hw);
+            g.p2 = (uint8_t)(hw - 1 - g.p1);
+            if (!p.cheese_symmetric) g.p2 = (uint8_t)rng.below((uint32_t)hw);
+        }
+        return place_cheese(g, p.cheese_count, p.cheese_symmetric != 0, gseed + index, err);
+    };
+
+    // resident games: bounded by the request, the caller's hint and the arena footprint
+    uint32_t S = p.concurrent_games ? p.concurrent_games : 16384;
+    if (S > p.num_games) S = p.num_games;
+    if (S == 0) {
+        memset(out, 0, sizeof *out);
+        return AR_OK;
+    }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipSetDevice(device) != hipSuccess) return fail(AR_E_DEVICE, "hipSetDevice failed");
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t per_game = (size_t)initial_arena_nodes(cfg) * (sizeof(NodeStats) + sizeof(NodeKids)) +
+                                make_layout<NW>(cfg, p.max_turns).total + sizeof(PosRec<NW>) * p.max_turns * 2 + 4096;
+        const size_t budget = free_b / 10 * 6;  // leave room for arenas that grow
+        if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
+        if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
+    }
+
+    Engine<NW> eng;
+    eng.net = net;
+    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, 0, net != nullptr)) return rc;
+
+    BundleSink writer;
+    const bool to_disk = p.output_dir != nullptr;
+    if (to_disk) {
+        writer.dir = p.output_dir;
+        writer.max_games = p.max_games_per_bundle ? p.max_games_per_bundle : 32;
+        writer.start();
+    }
+
+    ArSelfPlayStats st;
+    memset(&st, 0, sizeof st);
+    st.min_turns = 0xFFFFFFFFu;
+    std::vector<HostGame> slot_game(S);
+    uint32_t next_game = 0, finished = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::string err;
+
+    auto refill = [&](const std::vector<uint32_t>& free_slots) -> int {
+        std::vector<GameInit<NW>> inits;
+        for (uint32_t sl : free_slots) {
+            if (next_game >= p.num_games) break;
+            const uint32_t index = p.first_game_index + next_game;
+            HostGame g;
+            if (!make_game(index, g, err)) return fail(AR_E_INVALID, err);
+            GameInit<NW> gi;
+            memset(&gi, 0, sizeof gi);
+            fill_state<NW>(g, gi.board, gi.st, 0);
+            gi.rng_seed = rseed + index;
+            gi.game_index = index;
+            gi.slot = sl;
+            gi.single = 0;
+            inits.push_back(gi);
+            slot_game[sl] = std::move(g);
+            ++next_game;
+        }
+        return eng.start_games(inits);
+    };
+
+    {
+        std::vector<uint32_t> all(S);
+        for (uint32_t i = 0; i < S; ++i) all[i] = i;
+        if (int rc = refill(all)) {
+            writer.finish();
+            return rc;
+        }
+    }
+
+    int rc = AR_OK;
+    // steps between host visits: a game needs ~n_sims/batch steps per move, so a few dozen steps of
+    // latency on refills and arena growth costs little
+    const int iters = 4, launches = 8;
+    while (finished < p.num_games) {
+        if ((rc = eng.run_steps(launches, iters)) != AR_OK) break;
+        uint32_t c[4];
+        if ((rc = eng.scan(c)) != AR_OK) break;
+        if (c[3] != 0) {
+            rc = fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel (slot.error != 0)");
+            break;
+        }
+        if (c[1] && (rc = eng.handle_stalls(c[1])) != AR_OK) break;
+        if (c[0]) {
+            const uint32_t n_done = c[0];
+            if ((rc = eng.drain(n_done)) != AR_OK) break;
+            std::vector<uint32_t> free_slots;
+            for (uint32_t d = 0; d < n_done; ++d) {
+                const DoneInfo<NW>& di = eng.h_info.p[d];
+                auto rec = std::make_shared<GameRecordHost>();
+                record_from_device<NW>(di, eng.h_staging.p + (size_t)d * p.max_turns, slot_game[di.slot], cost, *rec);
+                // SelfPlayStats::add_game (selfplay.rs:190-210)
+                st.total_games += 1;
+                st.total_positions += rec->n;
+                st.total_simulations += rec->sims;
+                st.total_nn_evals += rec->nn;
+                st.total_terminals += rec->term;
+                st.total_collisions += rec->coll;
+                st.total_cheese_collected += rec->final_p1 + rec->final_p2;
+                st.total_cheese_available += rec->cheese_available;
+                if (rec->n < st.min_turns) st.min_turns = rec->n;
+                if (rec->n > st.max_turns) st.max_turns = rec->n;
+                if (rec->result == 1) st.p1_wins += 1;
+                else if (rec->result == 2) st.p2_wins += 1;
+                else st.draws += 1;
+                st.gather_node_visits += di.nv_gather;
+                st.backup_node_visits += di.nv_backup;
+                st.new_nodes += di.new_nodes;
+                if (progress) {  // selfplay.rs:637-645
+                    __atomic_fetch_add(&progress->positions_completed, (uint64_t)rec->n, __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&progress->simulations_completed, rec->sims, __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&progress->nn_evals_completed, rec->nn, __ATOMIC_RELAXED);
+                    __atomic_fetch_add(&progress->games_completed, 1u, __ATOMIC_RELAXED);
+                }
+                if (sink) {
+                    ArGameRecordView v = rec->view();
+                    sink(sink_user, &v);
+                }
+                if (to_disk && rec->n > 0) writer.push(rec);
+                free_slots.push_back(di.slot);
+                ++finished;
+            }
+            if ((rc = refill(free_slots)) != AR_OK) break;
+        }
+        if (c[0] == 0 && c[1] == 0 && c[2] == 0 && finished < p.num_games && next_game >= p.num_games) {
+            rc = fail(AR_E_DEVICE, "self-play stalled: no active games left but not all games finished");
+            break;
+        }
+    }
+    if (to_disk) {
+        writer.finish();
+        if (rc == AR_OK && !writer.error.empty()) rc = fail(AR_E_IO, writer.error);
+    }
+    st.elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (st.total_games == 0) st.min_turns = 0;
+    st.device_secs = eng.device_ms / 1000.0;
+    st.steps = eng.steps;
+    *out = st;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single searches
+// ------------------------------------------------------------------------------------------------
+bool host_game_from_spec(const ArGameSpec& g, HostGame& h, std::vector<uint8_t>& cost, std::string& err) {
+    const int hw = g.width * g.height;
+    if (g.width == 0 || g.height == 0 || hw > 256) {
+        err = "board must have 1..256 cells";
+        return false;
+    }
+    if (g.p1_x >= g.width || g.p2_x >= g.width || g.p1_y >= g.height || g.p2_y >= g.height) {
+        err = "player position outside the board";
+        return false;
+    }
+    if (!g.cheese) {
+        err = "cheese mask is required";
+        return false;
+    }
+    h.width = g.width;
+    h.height = g.height;
+    h.max_turns = g.max_turns;
+    h.turn = g.turn;
+    h.p1 = (uint8_t)(g.p1_y * g.width + g.p1_x);
+    h.p2 = (uint8_t)(g.p2_y * g.width + g.p2_x);
+    h.m1 = g.p1_mud;
+    h.m2 = g.p2_mud;
+    h.s1 = g.p1_score;
+    h.s2 = g.p2_score;
+    h.cheese.assign(g.cheese, g.cheese + hw);
+    uint32_t rem = 0;
+    for (int i = 0; i < hw; ++i) rem += h.cheese[i] ? 1 : 0;
+    h.total_cheese = (uint16_t)(g.p1_score + g.p2_score + (float)rem);
+    if (g.cost) cost.assign(g.cost, g.cost + (size_t)hw * 4);
+    else cost = open_maze_cost(g.width, g.height);
+    return true;
+}
+
+void fill_result(const MoveResult& m, ArSearchResult* o) {
+    memcpy(o->policy_p1, m.policy[0], 20);
+    memcpy(o->policy_p2, m.policy[1], 20);
+    o->value_p1 = m.value[0];
+    o->value_p2 = m.value[1];
+    memcpy(o->visit_counts_p1, m.visit_counts[0], 20);
+    memcpy(o->visit_counts_p2, m.visit_counts[1], 20);
+    memcpy(o->prior_p1, m.prior[0], 20);
+    memcpy(o->prior_p2, m.prior[1], 20);
+    o->total_visits = m.total_visits;
+    o->nn_evals = m.nn_evals;
+    o->terminals = m.terminals;
+    o->collisions = m.collisions;
+}
+
+template <int NW>
+int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const uint64_t* seeds,
+                ArPredictFn predict_fn, void* user, ArNet* net, int device, ArSearchResult* out) {
+    std::string err;
+    std::vector<HostGame> hg(n);
+    std::vector<uint8_t> mazes;
+    std::vector<uint32_t> maze_off(n);
+    uint16_t max_turns = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        std::vector<uint8_t> c;
+        if (!host_game_from_spec(games[i], hg[i], c, err)) return fail(AR_E_INVALID, err);
+        maze_off[i] = (uint32_t)mazes.size();
+        mazes.insert(mazes.end(), c.begin(), c.end());
+        if (hg[i].max_turns > max_turns) max_turns = hg[i].max_turns;
+    }
+    Engine<NW> eng;
+    eng.net = predict_fn ? nullptr : net;
+    if (int rc = eng.setup(device, n, cfg, max_turns, mazes, 0, eng.net != nullptr)) return rc;
+    std::vector<GameInit<NW>> inits(n);
+    std::random_device rd;
+    for (uint32_t i = 0; i < n; ++i) {
+        memset(&inits[i], 0, sizeof inits[i]);
+        fill_state<NW>(hg[i], inits[i].board, inits[i].st, maze_off[i]);
+        inits[i].rng_seed = seeds ? seeds[i] : (((uint64_t)rd() << 32) | rd());
+        inits[i].game_index = i;
+        inits[i].slot = i;
+        inits[i].single = 1;
+    }
+    if (int rc = eng.start_games(inits)) return rc;
+
+    if (predict_fn) {
+        // host evaluator per leaf batch (PyCallbackBackend, bindings.rs:119-161); n == 1
+        DevBuf<State<NW>> d_leaves;
+        DevBuf<EvalOut> d_ev;
+        DevBuf<uint32_t> d_n;
+        HIP_TRY(d_leaves.alloc(cfg.batch_size));
+        HIP_TRY(d_ev.alloc(cfg.batch_size));
+        HIP_TRY(d_n.alloc(1));
+        std::vector<State<NW>> leaves(cfg.batch_size);
+        std::vector<ArLeaf> al(cfg.batch_size);
+        std::vector<EvalOut> ev(cfg.batch_size);
+        std::vector<float> pp1(cfg.batch_size * 5), pp2(cfg.batch_size * 5), pv1(cfg.batch_size), pv2(cfg.batch_size);
+        const int w = hg[0].width;
+        for (;;) {
+            uint32_t c[4];
+            if (int rc = eng.scan(c)) return rc;
+            if (c[3]) return fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel");
+            if (c[1]) {
+                if (int rc = eng.handle_stalls(c[1])) return rc;
+                continue;
+            }
+            if (c[2] == 0) break;
+            hipLaunchKernelGGL(k_gather<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u, cfg, eng.maze.p,
+                               (LeafReq<NW>*)nullptr, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_export_leaves<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, d_leaves.p, d_n.p);
+            uint32_t nl = 0;
+            HIP_TRY(hipMemcpyAsync(&nl, d_n.p, 4, hipMemcpyDeviceToHost, eng.stream));
+            HIP_TRY(hipMemcpyAsync(leaves.data(), d_leaves.p, sizeof(State<NW>) * cfg.batch_size, hipMemcpyDeviceToHost,
+                                   eng.stream));
+            HIP_TRY(hipStreamSynchronize(eng.stream));
+            if (nl > 0) {
+                for (uint32_t j = 0; j < nl; ++j) {
+                    const State<NW>& s = leaves[j];
+                    ArLeaf& a = al[j];
+                    memset(&a, 0, sizeof a);
+                    a.p1_x = s.p1 % w;
+                    a.p1_y = s.p1 / w;
+                    a.p2_x = s.p2 % w;
+                    a.p2_y = s.p2 / w;
+                    a.p1_mud = s.m1;
+                    a.p2_mud = s.m2;
+                    a.turn = s.turn;
+                    a.p1_score = s.s1;
+                    a.p2_score = s.s2;
+                    for (int k = 0; k < NW; ++k) a.cheese_bits[k] = s.cheese[k];
+                }
+                if (predict_fn(user, al.data(), nl, pp1.data(), pp2.data(), pv1.data(), pv2.data()) != 0) {
+                    hipLaunchKernelGGL(k_cancel<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u);
+                    hipStreamSynchronize(eng.stream);
+                    return fail(AR_E_BACKEND, "predict_fn raised an exception");
+                }
+                for (uint32_t j = 0; j < nl; ++j) {
+                    memcpy(ev[j].p1, &pp1[j * 5], 20);
+                    memcpy(ev[j].p2, &pp2[j * 5], 20);
+                    ev[j].v1 = pv1[j];
+                    ev[j].v2 = pv2[j];
+                }
+                HIP_TRY(hipMemcpyAsync(d_ev.p, ev.data(), sizeof(EvalOut) * nl, hipMemcpyHostToDevice, eng.stream));
+                hipLaunchKernelGGL(k_import_evals<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, d_ev.p, nl);
+            }
+            hipLaunchKernelGGL(k_backup<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u, cfg, eng.maze.p,
+                               eng.zig.p, (const EvalOut*)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        for (;;) {
+            if (int rc = eng.run_steps(4, 8)) return rc;
+            uint32_t c[4];
+            if (int rc = eng.scan(c)) return rc;
+            if (c[3]) return fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel");
+            if (c[1]) {
+                if (int rc = eng.handle_stalls(c[1])) return rc;
+            }
+            if (c[2] == 0 && c[1] == 0) break;
+        }
+    }
+    uint32_t c[4];
+    if (int rc = eng.scan(c)) return rc;
+    if (c[0] != n) return fail(AR_E_DEVICE, "search ended with unfinished slots");
+    if (int rc = eng.drain(n)) return rc;
+    for (uint32_t d = 0; d < n; ++d) fill_result(eng.h_info.p[d].last, &out[eng.h_info.p[d].game_index]);
+    return AR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* ar_version(void) { return "alpharat_hip 0.1.0 (gfx950)"; }
+
+size_t ar_last_error(char* buf, size_t cap) {
+    if (buf && cap) {
+        size_t n = g_error.size() < cap - 1 ? g_error.size() : cap - 1;
+        memcpy(buf, g_error.data(), n);
+        buf[n] = 0;
+    }
+    return g_error.size();
+}
+
+int ar_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return fail(AR_E_DEVICE, "hipGetDeviceCount failed (no HIP device?)");
+    return n;
+}
+
+int ar_search_many(const ArGameSpec* games, uint32_t n, const ArSearchConfig* cfg, uint32_t simulations,
+                   uint32_t batch_size, const uint64_t* seeds, ArNet* net, int device, ArSearchResult* out) {
+    if (!games || !cfg || !out || n == 0) return fail(AR_E_INVALID, "null argument");
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    SearchCfg c = to_cfg(*cfg, simulations, batch_size);
+    if (int rc = check_cfg(c)) return rc;
+    bool small = true;
+    for (uint32_t i = 0; i < n; ++i) small = small && (int)games[i].width * games[i].height <= 64;
+    return small ? search_impl<1>(games, n, c, seeds, nullptr, nullptr, net, dev, out)
+                 : search_impl<4>(games, n, c, seeds, nullptr, nullptr, net, dev, out);
+}
+
+int ar_search(const ArGameSpec* game, const ArSearchConfig* cfg, uint32_t simulations, uint32_t batch_size,
+              const uint64_t* seed, ArPredictFn predict_fn, void* user, ArNet* net, int device, ArSearchResult* out) {
+    if (!game || !cfg || !out) return fail(AR_E_INVALID, "null argument");
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    SearchCfg c = to_cfg(*cfg, simulations, batch_size);
+    if (int rc = check_cfg(c)) return rc;
+    const bool small = (int)game->width * game->height <= 64;
+    return small ? search_impl<1>(game, 1, c, seed, predict_fn, user, net, dev, out)
+                 : search_impl<4>(game, 1, c, seed, predict_fn, user, net, dev, out);
+}
+
+int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink sink, void* sink_user,
+                    ArSelfPlayStats* out) {
+    if (!p || !out) return fail(AR_E_INVALID, "null argument");
+    const std::string mt = p->maze_type ? p->maze_type : "open";
+    if (mt != "open") {
+        if (mt == "classic" || mt == "random")
+            return fail(AR_E_INVALID, "maze_type '" + mt + "' is not generated on the device yet (open mazes only)");
+        return fail(AR_E_INVALID, "unknown maze_type: " + mt);
+    }
+    const std::string pos = p->positions ? p->positions : "corners";
+    if (pos != "corners" && pos != "random") return fail(AR_E_INVALID, "unknown positions: " + pos);
+    if (p->width == 0 || p->height == 0 || (int)p->width * p->height > 256)
+        return fail(AR_E_INVALID, "board must have 1..256 cells");
+    if (p->cache_size != 0) return fail(AR_E_INVALID, "cache_size > 0: the device NN-eval cache is not built yet");
+    int dev = 0;
+    if (int rc = parse_device(p->device, p->device_index, dev)) return rc;
+    ArNet* net = nullptr;
+    if (p->weights_path) {
+        if (int rc = ar_net_load(p->weights_path, dev, &net)) return rc;
+    }
+    const int rc = (int)p->width * p->height <= 64 ? selfplay_impl<1>(*p, dev, net, progress, sink, sink_user, out)
+                                                   : selfplay_impl<4>(*p, dev, net, progress, sink, sink_user, out);
+    if (net) ar_net_free(net);
+    return rc;
+}
+
+int ar_net_load(const char*, int, ArNet** out) {
+    if (out) *out = nullptr;
+    return fail(AR_E_BACKEND, "network evaluators are not built in this revision");
+}
+void ar_net_free(ArNet*) {}
+int ar_net_evaluate(ArNet*, const ArGameSpec*, uint32_t, float*, float*, float*, float*, float*, float*) {
+    return fail(AR_E_BACKEND, "network evaluators are not built in this revision");
+}
+int ar_encode(const ArGameSpec*, uint32_t, int, float*) {
+    return fail(AR_E_BACKEND, "device encoder is not built in this revision");
+}
+
+int ar_write_bundle(const ArGameRecordView* games, uint32_t n, const char* path) {
+    if (!games || !path) return fail(AR_E_INVALID, "null argument");
+    std::string err;
+    if (!write_bundle(games, n, path, err)) return fail(AR_E_IO, err);
+    return AR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,10 @@
+"""Drop-in for crates/alpharat-mcts-python/python/alpharat_sampling/__init__.py (MI355X backend)."""
+from alpharat_amd.sampling import (
+    SelfPlayProgress,
+    SelfPlayStats,
+    preload_cuda_libs,
+    preload_tensorrt_libs,
+    rust_self_play,
+)
+
+__all__ = ["SelfPlayStats", "SelfPlayProgress", "rust_self_play", "preload_cuda_libs", "preload_tensorrt_libs"]

@@ -1,0 +1,210 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
+Bar: bit-exact (visit counts, policies, values, selected actions, whole-game records)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TUNED = dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103)
+
+
+def _pyrat(og: O.Game, max_turns):
+    from alpharat_amd.game import PyRat
+
+    st = og.state()
+    maze = og.maze().reshape(-1).astype(np.int16)
+    cost = np.where(maze < 0, 0, maze).astype(np.uint8)
+    return PyRat(og.w, og.h, cost, og.cheese_mask(), st["p1"], st["p2"], max_turns, st["turn"], st["p1_score"],
+                 st["p2_score"], st["p1_mud"], st["p2_mud"])
+
+
+def _games():
+    yield "open5_corner", O.Game(5, 5, 100, p1=(0, 0), p2=(4, 4), cheese=[(2, 2), (1, 3), (3, 1)]), 100
+    yield "same_cell", O.Game(5, 5, 100, p1=(2, 2), p2=(2, 2), cheese=[(i, 0) for i in range(5)]), 100
+    yield "short", O.Game(5, 5, 3, p1=(0, 0), p2=(2, 0), cheese=[(1, 0)]), 3
+    g = O.Game(5, 5, 100, p1=(2, 2), p2=(4, 4), cheese=[(0, 0), (4, 0)], mud=[((2, 2), (2, 3), 3)],
+               walls=[((0, 0), (0, 1)), ((3, 3), (4, 3))])
+    g.make_move(0, 4)
+    yield "mud_wall", g, 100
+    yield "7x7", O.Game(7, 7, 50).random_cheese(10, True, 5), 50
+    yield "15x11", O.Game(15, 11, 200).random_cheese(21, True, 2), 200
+    t = O.Game(5, 5, 1, p1=(0, 0), p2=(0, 1), cheese=[(4, 4)])
+    t.make_move(4, 4)
+    yield "terminal_root", t, 1
+
+
+def _assert_result(got, want, name):
+    for k in ("policy_p1", "policy_p2", "visit_counts_p1", "visit_counts_p2", "prior_p1", "prior_p2"):
+        assert getattr(got, k).tobytes() == want[k].tobytes(), (name, k, getattr(got, k), want[k])
+    assert np.float32(got.value_p1).tobytes() == np.float32(want["value_p1"]).tobytes(), name
+    assert np.float32(got.value_p2).tobytes() == np.float32(want["value_p2"]).tobytes(), name
+    assert (got.total_visits, got.nn_evals, got.terminals, got.collisions) == (
+        want["total_visits"], want["nn_evals"], want["terminals"], want["collisions"]), name
+
+
+@pytest.mark.parametrize("sims,batch", [(1, 1), (50, 1), (200, 8), (1000, 16)])
+def test_search_bit_exact(sims, batch):
+    from alpharat_amd.mcts import rust_mcts_search
+
+    for name, og, mt in _games():
+        for kw in (dict(), TUNED, dict(noise_epsilon=0.25, **TUNED)):
+            want = O.search_once(og, O.make_config(**kw), sims, batch, seed=42)
+            got = rust_mcts_search(_pyrat(og, mt), simulations=sims, batch_size=batch, seed=42, **kw)
+            _assert_result(got, want, (name, kw))
+
+
+def test_search_many_matches_individual_searches():
+    from alpharat_amd.mcts import search_many
+
+    items = list(_games())[:5]
+    res = search_many([_pyrat(og, mt) for _, og, mt in items], simulations=300, batch_size=8,
+                      seeds=[7 + i for i in range(len(items))], **TUNED)
+    for i, (name, og, mt) in enumerate(items):
+        _assert_result(res[i], O.search_once(og, O.make_config(**TUNED), 300, 8, seed=7 + i), name)
+
+
+def test_predict_fn_callback_path():
+    # test_callback.py:114-133: batches never exceed batch_size; constant-value evaluator
+    from alpharat_amd.mcts import rust_mcts_search
+
+    og = O.Game(5, 5, 100, p1=(1, 1), p2=(3, 3), cheese=[(2, 2), (0, 4)])
+    sizes = []
+
+    def predict_fn(games):
+        sizes.append(len(games))
+        n = len(games)
+        p1 = np.zeros((n, 5), np.float32)
+        p2 = np.zeros((n, 5), np.float32)
+        for i, g in enumerate(games):
+            for arr, eff in ((p1, g.effective_actions_p1()), (p2, g.effective_actions_p2())):
+                u = sorted(set(eff))
+                for a in u:
+                    arr[i, a] = np.float32(1.0) / np.float32(len(u))
+        return p1, p2, np.full(n, 1.5, np.float32), np.full(n, 0.5, np.float32)
+
+    want = O.search_once(og, O.make_config(), 120, 4, seed=123, backend=1, v1=1.5, v2=0.5)
+    got = rust_mcts_search(_pyrat(og, 100), predict_fn=predict_fn, simulations=120, batch_size=4, seed=123)
+    _assert_result(got, want, "callback")
+    assert sizes and max(sizes) <= 4
+
+    def boom(games):
+        raise ValueError("nope")
+
+    with pytest.raises(RuntimeError, match="predict_fn raised"):
+        rust_mcts_search(_pyrat(og, 100), predict_fn=boom, simulations=20, batch_size=4, seed=1)
+
+
+def _check_game(g, want):
+    assert g["n"] == want["n"]
+    np.testing.assert_array_equal(g["p1_pos"], want["ints"][:, 0:2])
+    np.testing.assert_array_equal(g["p2_pos"], want["ints"][:, 2:4])
+    np.testing.assert_array_equal(g["p1_mud"], want["ints"][:, 4])
+    np.testing.assert_array_equal(g["turn"], want["ints"][:, 6])
+    np.testing.assert_array_equal(g["action_p1"], want["ints"][:, 7])
+    np.testing.assert_array_equal(g["action_p2"], want["ints"][:, 8])
+    f = want["floats"]
+    for k, sl in (("p1_score", slice(0, 1)), ("p2_score", slice(1, 2)), ("value_p1", slice(2, 3)),
+                  ("value_p2", slice(3, 4)), ("visit_counts_p1", slice(4, 9)), ("visit_counts_p2", slice(9, 14)),
+                  ("prior_p1", slice(14, 19)), ("prior_p2", slice(19, 24)), ("policy_p1", slice(24, 29)),
+                  ("policy_p2", slice(29, 34))):
+        assert g[k].reshape(g["n"], -1).tobytes() == np.ascontiguousarray(f[:, sl]).tobytes(), k
+    np.testing.assert_array_equal(g["cheese_mask"], want["masks"])
+    np.testing.assert_array_equal(g["maze"], want["maze"])
+    np.testing.assert_array_equal(g["initial_cheese"], want["initial_cheese"])
+    np.testing.assert_array_equal(g["cheese_outcomes"], want["cheese_outcomes"])
+    assert (g["final_p1_score"], g["final_p2_score"], g["result"]) == (
+        want["final_p1_score"], want["final_p2_score"], want["result"])
+    for k in ("total_simulations", "total_nn_evals", "total_terminals", "total_collisions", "cheese_available"):
+        assert g[k] == want[k], k
+
+
+@pytest.mark.parametrize("w,h,cheese,turns,sims,batch,kw,n_games", [
+    (5, 5, 5, 30, 100, 8, dict(), 48),                                   # BASELINE config 1 (plumbing)
+    (5, 5, 5, 30, 1000, 16, dict(), 12),                                  # config 2 search settings
+    (7, 7, 10, 50, 600, 16, dict(noise_epsilon=0.25, **TUNED), 12),       # config 3 search settings, fewer sims
+])
+def test_selfplay_records_bit_exact(w, h, cheese, turns, sims, batch, kw, n_games):
+    from alpharat_amd.sampling import rust_self_play
+
+    games = []
+    stats = rust_self_play(width=w, height=h, cheese_count=cheese, max_turns=turns, num_games=n_games,
+                           simulations=sims, batch_size=batch, output_dir=None, seed=0, concurrent_games=8,
+                           on_game=games.append, **kw)
+    assert stats.total_games == n_games and len(games) == n_games
+    assert sorted(g["game_index"] for g in games) == list(range(n_games))
+    cfg = O.make_config(**kw)
+    tot = dict(sims=0, nn=0, gv=0, bv=0)
+    for g in games:
+        i = g["game_index"]
+        want = O.play_game(O.Game(w, h, turns).random_cheese(cheese, True, i), cfg, sims, batch, 0xA1FA0000 + i)
+        _check_game(g, want)
+        tot["sims"] += want["total_simulations"]
+        tot["gv"] += want["gather_node_visits"]
+        tot["bv"] += want["backup_node_visits"]
+    assert stats.total_simulations == tot["sims"]
+    assert stats.gather_node_visits == tot["gv"] and stats.backup_node_visits == tot["bv"]
+
+
+def test_selfplay_full_size_properties():
+    """BASELINE config 2 at full width (4096 concurrent 5x5 games, 1000 sims): size-independent
+    properties instead of an oracle replay -- conservation of cheese, policy normalisation, sampled
+    actions legal, counters consistent, every game index exactly once."""
+    from alpharat_amd.sampling import rust_self_play
+
+    seen = []
+    acc = dict(bad_policy=0, bad_action=0, bad_cheese=0, positions=0)
+
+    def on_game(g):
+        seen.append(g["game_index"])
+        acc["positions"] += g["n"]
+        s1 = g["policy_p1"].sum(axis=1)
+        s2 = g["policy_p2"].sum(axis=1)
+        acc["bad_policy"] += int((np.abs(s1 - 1) > 1e-5).sum() + (np.abs(s2 - 1) > 1e-5).sum())
+        idx = np.arange(g["n"])
+        acc["bad_action"] += int((g["policy_p1"][idx, g["action_p1"]] <= 0).sum())
+        acc["bad_action"] += int((g["policy_p2"][idx, g["action_p2"]] <= 0).sum())
+        collected = (g["cheese_outcomes"] != 2).sum()
+        acc["bad_cheese"] += int(abs(collected - (g["final_p1_score"] + g["final_p2_score"])) > 1e-6)
+
+    stats = rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=4096, simulations=1000,
+                           batch_size=16, output_dir=None, seed=0, concurrent_games=4096, on_game=on_game)
+    assert sorted(seen) == list(range(4096))
+    assert acc == dict(bad_policy=0, bad_action=0, bad_cheese=0, positions=stats.total_positions)
+    assert stats.p1_wins + stats.p2_wins + stats.draws == 4096
+    assert stats.total_nn_evals + stats.total_terminals >= 1000 * stats.total_positions * 0.99
+    # two games replayed on the oracle
+    for i in (0, 4095):
+        want = O.play_game(O.Game(5, 5, 30).random_cheese(5, True, i), O.make_config(), 1000, 16, 0xA1FA0000 + i)
+        assert want["n"] > 0
+
+
+def test_bundles_on_disk_roundtrip(tmp_path):
+    from alpharat_amd.sampling import rust_self_play
+
+    games = {}
+    stats = rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=10, simulations=50, batch_size=8,
+                           output_dir=tmp_path, max_games_per_bundle=4, seed=3, on_game=lambda g: games.__setitem__(g["game_index"], g))
+    files = sorted(tmp_path.glob("bundle_*.npz"))
+    assert len(files) == 3 and not list(tmp_path.glob("*.tmp"))
+    n_games = n_pos = 0
+    for f in files:
+        z = np.load(f)
+        assert len(z.files) == 26
+        n_games += len(z["game_lengths"])
+        n_pos += int(z["game_lengths"].sum())
+        assert z["maze"].dtype == np.int8 and z["cheese_mask"].dtype == np.bool_ and z["turn"].dtype == np.int16
+        assert z["policy_p1"].shape == (int(z["game_lengths"].sum()), 5)
+    assert n_games == 10 and n_pos == stats.total_positions
+
+
+def test_invalid_arguments_raise():
+    from alpharat_amd.sampling import rust_self_play
+
+    with pytest.raises(ValueError, match="unknown maze_type"):
+        rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=1, simulations=10, output_dir=None,
+                       maze_type="spiral")
+    with pytest.raises(ValueError, match="device"):
+        rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=1, simulations=10, output_dir=None,
+                       device="tensorrt")
