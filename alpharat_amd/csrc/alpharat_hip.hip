@@ -476,6 +476,7 @@ struct Engine {
     double device_ms = 0.0;
     uint64_t steps = 0;
     uint64_t grows = 0;
+    bool timed = false;
     ArNet* net = nullptr;
 
     ~Engine() {
@@ -528,6 +529,11 @@ struct Engine {
             HIP_TRY(ev_queue.alloc((size_t)S * cfg.batch_size));
             HIP_TRY(queue_count.alloc(1));
         }
+        if (net != nullptr) {
+            const size_t per = (size_t)net->dev.hw * 4;
+            if (maze_bytes.size() % per != 0) return fail(AR_E_INVALID, "maze pool does not match the network's board size");
+            if (int rc = net_bind_mazes(net, maze.p, (int)(maze_bytes.size() / per), stream)) return rc;
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         return AR_OK;
     }
@@ -570,6 +576,7 @@ struct Engine {
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));
+        timed = true;
         return AR_OK;
     }
 
@@ -581,8 +588,11 @@ struct Engine {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
+        if (timed) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
+            timed = false;
+        }
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
         return AR_OK;
     }
@@ -1223,16 +1233,139 @@ int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink 
     return rc;
 }
 
-int ar_net_load(const char*, int, ArNet** out) {
-    if (out) *out = nullptr;
-    return fail(AR_E_BACKEND, "network evaluators are not built in this revision");
+int ar_net_load(const char* blob_path, int device, ArNet** out) {
+    if (!blob_path || !out) return fail(AR_E_INVALID, "null argument");
+    *out = nullptr;
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    arnet::Blob blob;
+    std::string err;
+    if (!blob.load(blob_path, err)) return fail(AR_E_IO, err);
+    std::unique_ptr<ArNet> net(new ArNet());
+    net->device = dev;
+    if (int rc = net_build(blob, net.get())) return rc;
+    *out = net.release();
+    return AR_OK;
 }
-void ar_net_free(ArNet*) {}
-int ar_net_evaluate(ArNet*, const ArGameSpec*, uint32_t, float*, float*, float*, float*, float*, float*) {
-    return fail(AR_E_BACKEND, "network evaluators are not built in this revision");
+
+void ar_net_free(ArNet* net) { delete net; }
+
+}  // extern "C"
+
+namespace {
+template <int NW>
+int specs_to_device(const ArGameSpec* games, uint32_t n, std::vector<LeafReq<NW>>& reqs, std::vector<Board>& boards,
+                    std::vector<uint8_t>& mazes) {
+    std::string err;
+    reqs.resize(n);
+    boards.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        HostGame hg;
+        std::vector<uint8_t> c;
+        if (!host_game_from_spec(games[i], hg, c, err)) return fail(AR_E_INVALID, err);
+        memset(&reqs[i], 0, sizeof reqs[i]);
+        fill_state<NW>(hg, boards[i], reqs[i].st, (uint32_t)mazes.size());
+        reqs[i].slot = i;
+        mazes.insert(mazes.end(), c.begin(), c.end());
+    }
+    return AR_OK;
 }
-int ar_encode(const ArGameSpec*, uint32_t, int, float*) {
-    return fail(AR_E_BACKEND, "device encoder is not built in this revision");
+
+template <int NW>
+int net_evaluate_impl(ArNet* net, const ArGameSpec* games, uint32_t n, float* pp1, float* pp2, float* pv1, float* pv2,
+                      float* lg1, float* lg2) {
+    std::vector<LeafReq<NW>> reqs;
+    std::vector<Board> boards;
+    std::vector<uint8_t> mazes;
+    if (int rc = specs_to_device<NW>(games, n, reqs, boards, mazes)) return rc;
+    for (uint32_t i = 0; i < n; ++i)
+        if (games[i].width != net->dev.width || games[i].height != net->dev.height)
+            return fail(AR_E_INVALID, "game size does not match the network's board size");
+    HIP_TRY(hipSetDevice(net->device));
+    DevBuf<LeafReq<NW>> d_req;
+    DevBuf<Board> d_boards;
+    DevBuf<uint8_t> d_maze;
+    DevBuf<EvalOut> d_out;
+    DevBuf<float> d_logits;
+    HIP_TRY(d_req.alloc(n));
+    HIP_TRY(d_boards.alloc(n));
+    HIP_TRY(d_maze.alloc(mazes.size()));
+    HIP_TRY(d_out.alloc(n));
+    HIP_TRY(d_logits.alloc((size_t)n * 10));
+    HIP_TRY(hipMemcpy(d_req.p, reqs.data(), sizeof(LeafReq<NW>) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_boards.p, boards.data(), sizeof(Board) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_maze.p, mazes.data(), mazes.size(), hipMemcpyHostToDevice));
+    if (int rc = net_bind_mazes(net, d_maze.p, (int)n, nullptr)) return rc;
+    int rc = net_launch<NW>(net, d_req.p, nullptr, n, (const char*)d_boards.p, sizeof(Board), d_out.p, d_logits.p, nullptr);
+    if (rc != AR_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    net->bound_pool = nullptr;  // the pool above dies with this call
+    std::vector<EvalOut> out(n);
+    std::vector<float> logits((size_t)n * 10);
+    HIP_TRY(hipMemcpy(out.data(), d_out.p, sizeof(EvalOut) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(logits.data(), d_logits.p, logits.size() * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(pp1 + (size_t)i * 5, out[i].p1, 20);
+        memcpy(pp2 + (size_t)i * 5, out[i].p2, 20);
+        pv1[i] = out[i].v1;
+        pv2[i] = out[i].v2;
+        if (lg1) memcpy(lg1 + (size_t)i * 5, &logits[(size_t)i * 10], 20);
+        if (lg2) memcpy(lg2 + (size_t)i * 5, &logits[(size_t)i * 10 + 5], 20);
+    }
+    return AR_OK;
+}
+
+template <int NW>
+int encode_impl(const ArGameSpec* games, uint32_t n, float* obs) {
+    std::vector<LeafReq<NW>> reqs;
+    std::vector<Board> boards;
+    std::vector<uint8_t> mazes;
+    if (int rc = specs_to_device<NW>(games, n, reqs, boards, mazes)) return rc;
+    int dim = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const int d = games[i].width * games[i].height * 7 + 6;
+        if (i && d != dim) return fail(AR_E_INVALID, "ar_encode: all games must have the same board size");
+        dim = d;
+    }
+    DevBuf<LeafReq<NW>> d_req;
+    DevBuf<Board> d_boards;
+    DevBuf<uint8_t> d_maze;
+    DevBuf<float> d_obs;
+    HIP_TRY(d_req.alloc(n));
+    HIP_TRY(d_boards.alloc(n));
+    HIP_TRY(d_maze.alloc(mazes.size()));
+    HIP_TRY(d_obs.alloc((size_t)n * dim));
+    HIP_TRY(hipMemcpy(d_req.p, reqs.data(), sizeof(LeafReq<NW>) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_boards.p, boards.data(), sizeof(Board) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_maze.p, mazes.data(), mazes.size(), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(arnet::k_encode<NW>, dim3(n), dim3(128), 0, nullptr, d_req.p, n, d_boards.p, d_maze.p, d_obs.p, dim);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(obs, d_obs.p, (size_t)n * dim * 4, hipMemcpyDeviceToHost));
+    return AR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ar_net_evaluate(ArNet* net, const ArGameSpec* games, uint32_t n, float* policy_p1, float* policy_p2,
+                    float* value_p1, float* value_p2, float* logits_p1, float* logits_p2) {
+    if (!net || !games || !policy_p1 || !policy_p2 || !value_p1 || !value_p2) return fail(AR_E_INVALID, "null argument");
+    if (n == 0) return AR_OK;
+    return net->dev.hw <= 64
+               ? net_evaluate_impl<1>(net, games, n, policy_p1, policy_p2, value_p1, value_p2, logits_p1, logits_p2)
+               : net_evaluate_impl<4>(net, games, n, policy_p1, policy_p2, value_p1, value_p2, logits_p1, logits_p2);
+}
+
+int ar_encode(const ArGameSpec* games, uint32_t n, int device, float* obs) {
+    if (!games || !obs) return fail(AR_E_INVALID, "null argument");
+    if (n == 0) return AR_OK;
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    bool small = true;
+    for (uint32_t i = 0; i < n; ++i) small = small && (int)games[i].width * games[i].height <= 64;
+    return small ? encode_impl<1>(games, n, obs) : encode_impl<4>(games, n, obs);
 }
 
 int ar_write_bundle(const ArGameRecordView* games, uint32_t n, const char* path) {

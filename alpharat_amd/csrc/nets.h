@@ -1,21 +1,571 @@
-// Device policy/value heads -- placeholder until the HIP evaluators land (next commit): the entry
-// points exist and fail loudly, they never fall back to another evaluator.
+// Policy/value heads as HIP kernels: PyRatMLP and SymmetricMLP (fp32), fused with the flat
+// observation encoder. Replaces FlatEncoder + OnnxBackend / TensorrtBackend
+// (crates/alpharat-sampling/src/flat_encoder.rs:52-125, backends/onnx.rs:176-246,
+// backends/tensorrt.rs:423 ff.) and restates `model.predict()` of
+// alpharat/nn/models/mlp.py:120-153 and alpharat/nn/models/symmetric.py:124-229 in eval mode.
+//
+// What the kernels exploit (none of it changes results beyond fp32 summation order):
+//   * BatchNorm (eval) is folded into the preceding Linear at load time.
+//   * The observation is never materialised for the network: its maze block is the same for every
+//     leaf of a maze, so its product with the first layer is a per-maze constant vector; the
+//     player one-hots select one weight column each; the cheese mask selects <= n_cheese columns;
+//     six scalars scale six columns. First layer cost: ~(8 + n_cheese) x H instead of D x H MACs.
+//   * Weights are stored transposed ([in][out]) so the 256 threads of a block (one per output
+//     neuron) read them coalesced; a block evaluates a tile of leaves so each weight fetched from
+//     L2 is reused across the tile; activations live in LDS and are read as broadcasts.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
 
+#include <map>
 #include <string>
+#include <vector>
 
 #include "../../include/alpharat_hip.h"
 #include "dev_search.h"
 
-struct ArNet {
-    int device;
-};
-
 static int nets_fail(int code, const std::string& msg);
 
+namespace arnet {
+
+enum { ARCH_MLP = 0, ARCH_SYMMETRIC = 1, ARCH_CNN = 2 };
+static const int TILE_MLP = 32;  // leaves per block
+static const int TILE_SYM = 16;
+static const int NTHREADS = 256;
+
+// Device-side weight views (all fp32, BN folded, transposed to [in][out])
+struct NetDev {
+    int arch, width, height, hw, H;
+    // MLP: l1 = trunk.0 (+trunk.1), l2 = trunk.4 (+trunk.5), head rows: p1[5] p2[5] v[2]
+    // SYM: l1 = shared_encoder, lp = player_encoder, l2 = trunk.0 (K = 2H), l3 = trunk.4,
+    //      head rows: policy[5] value[1] over K = 2H
+    const float *w1t, *b1;   // [D1][H]
+    const float *wpt, *bp;   // [hw+2][H]        (symmetric only)
+    const float *w2t, *b2;   // [K2][H]
+    const float *w3t, *b3;   // [H][H]           (symmetric only)
+    const float *wh, *bh;    // [n_head][Kh] row-major
+    int n_head, Kh;
+    const float* cmaze;      // [n_mazes][H] first-layer maze contribution incl. bias
+    int n_mazes;
+};
+
+struct Blob {
+    uint32_t arch = 0, width = 0, height = 0;
+    std::map<std::string, std::vector<float>> t;
+    std::map<std::string, std::vector<uint32_t>> dims;
+    bool load(const char* path, std::string& err) {
+        FILE* f = fopen(path, "rb");
+        if (!f) {
+            err = std::string("cannot open weight blob ") + path;
+            return false;
+        }
+        char magic[8];
+        uint32_t n = 0;
+        bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "ARNET001", 8) == 0 && fread(&arch, 4, 1, f) == 1 &&
+                  fread(&width, 4, 1, f) == 1 && fread(&height, 4, 1, f) == 1 && fread(&n, 4, 1, f) == 1;
+        for (uint32_t i = 0; ok && i < n; ++i) {
+            uint32_t nl = 0, nd = 0;
+            ok = fread(&nl, 4, 1, f) == 1 && nl < 4096;
+            std::string name(ok ? nl : 0, '\0');
+            ok = ok && fread(&name[0], 1, nl, f) == nl && fread(&nd, 4, 1, f) == 1 && nd <= 8;
+            std::vector<uint32_t> d(ok ? nd : 0);
+            size_t cnt = 1;
+            for (uint32_t k = 0; ok && k < nd; ++k) {
+                ok = fread(&d[k], 4, 1, f) == 1;
+                cnt *= d[k];
+            }
+            if (ok) {
+                std::vector<float> v(cnt);
+                ok = fread(v.data(), 4, cnt, f) == cnt;
+                t[name] = std::move(v);
+                dims[name] = d;
+            }
+        }
+        fclose(f);
+        if (!ok) err = std::string("malformed weight blob ") + path;
+        return ok;
+    }
+    const std::vector<float>* get(const std::string& k) const {
+        auto it = t.find(k);
+        return it == t.end() ? nullptr : &it->second;
+    }
+};
+
+// Linear (+ eval BatchNorm) -> transposed weights [in][out] and bias [out]
+inline bool fold_linear(const Blob& b, const std::string& lin, const std::string& bn, std::vector<float>& wt,
+                        std::vector<float>& bias, uint32_t& in, uint32_t& out, std::string& err) {
+    const std::vector<float>* w = b.get(lin + ".weight");
+    const std::vector<float>* bi = b.get(lin + ".bias");
+    if (!w || b.dims.at(lin + ".weight").size() != 2) {
+        err = "weight blob lacks " + lin + ".weight";
+        return false;
+    }
+    out = b.dims.at(lin + ".weight")[0];
+    in = b.dims.at(lin + ".weight")[1];
+    std::vector<double> scale(out, 1.0), shift(out, 0.0);
+    if (!bn.empty()) {
+        const std::vector<float>*g = b.get(bn + ".weight"), *be = b.get(bn + ".bias"), *m = b.get(bn + ".running_mean"),
+                          *v = b.get(bn + ".running_var");
+        if (!g || !be || !m || !v) {
+            err = "weight blob lacks " + bn + " statistics";
+            return false;
+        }
+        for (uint32_t o = 0; o < out; ++o) {
+            scale[o] = (double)(*g)[o] / sqrt((double)(*v)[o] + 1e-5);
+            shift[o] = (double)(*be)[o] - (double)(*m)[o] * scale[o];
+        }
+    }
+    wt.assign((size_t)in * out, 0.0f);
+    bias.assign(out, 0.0f);
+    for (uint32_t o = 0; o < out; ++o) {
+        for (uint32_t i = 0; i < in; ++i) wt[(size_t)i * out + o] = (float)((double)(*w)[(size_t)o * in + i] * scale[o]);
+        bias[o] = (float)((bi ? (double)(*bi)[o] : 0.0) * scale[o] + shift[o]);
+    }
+    return true;
+}
+
+// ---- device helpers ---------------------------------------------------------------------------
+// one leaf's sparse first-layer inputs
+struct LeafFeat {
+    int p1, p2;          // cells
+    float sc[6];         // score_diff, progress, p1_mud, p2_mud, p1_score, p2_score (flat_encoder.rs:114-123)
+    int maze_id;
+};
+
 template <int NW>
-static int net_forward_queue(ArNet*, const ar::LeafReq<NW>*, const uint32_t*, uint32_t, const ar::Slot<NW>*,
-                             const uint8_t*, ar::EvalOut*, hipStream_t) {
-    return nets_fail(AR_E_BACKEND, "network evaluators are not built in this revision");
+__device__ inline void leaf_features(const ar::State<NW>& st, const ar::Board& b, int hw, LeafFeat& f) {
+    f.p1 = st.p1;
+    f.p2 = st.p2;
+    f.sc[0] = st.s1 - st.s2;
+    f.sc[1] = b.max_turns > 0 ? (float)st.turn / (float)b.max_turns : 0.0f;
+    f.sc[2] = (float)st.m1 / 10.0f;
+    f.sc[3] = (float)st.m2 / 10.0f;
+    f.sc[4] = st.s1 / 10.0f;
+    f.sc[5] = st.s2 / 10.0f;
+    f.maze_id = (int)(b.maze_off / (uint32_t)(hw * 4));
+}
+
+// acc[l] += sum_k wt[k*H + n] * act[l*ld + k]   (act in LDS, broadcast reads)
+template <int L>
+__device__ inline void dense_acc(const float* __restrict__ wt, int K, int H, int n, const float* act, int ld,
+                                 float* acc) {
+    for (int k = 0; k < K; k += 4) {
+        const float w0 = wt[(size_t)(k + 0) * H + n], w1 = wt[(size_t)(k + 1) * H + n];
+        const float w2 = wt[(size_t)(k + 2) * H + n], w3 = wt[(size_t)(k + 3) * H + n];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const float4 a = *(const float4*)(act + (size_t)l * ld + k);
+            acc[l] = fmaf(w3, a.w, fmaf(w2, a.z, fmaf(w1, a.y, fmaf(w0, a.x, acc[l]))));
+        }
+    }
+}
+
+__device__ inline void softmax5(const float* l, float* p) {
+    float mx = l[0];
+    for (int i = 1; i < 5; ++i) mx = fmaxf(mx, l[i]);
+    float e[5], s = 0.0f;
+    for (int i = 0; i < 5; ++i) {
+        e[i] = expf(l[i] - mx);
+        s += e[i];
+    }
+    for (int i = 0; i < 5; ++i) p[i] = e[i] / s;
+}
+__device__ inline float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// per-maze first-layer constant: cmaze[m][n] = b1[n] + sum_{i < hw*4} maze_val(i) * w1t[i][n]
+__global__ void k_maze_const(const float* w1t, const float* b1, int H, int hw, const uint8_t* maze_pool, int n_mazes,
+                             float* cmaze) {
+    const int m = blockIdx.x;
+    if (m >= n_mazes) return;
+    const uint8_t* cost = maze_pool + (size_t)m * hw * 4;
+    for (int n = threadIdx.x; n < H; n += blockDim.x) {
+        float acc = b1[n];
+        for (int i = 0; i < hw * 4; ++i) {
+            const uint8_t c = cost[i];
+            const float v = c ? (float)c / 10.0f : -1.0f;
+            acc = fmaf(v, w1t[(size_t)i * H + n], acc);
+        }
+        cmaze[(size_t)m * H + n] = acc;
+    }
+}
+
+// ---- PyRatMLP ---------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                  uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                  ar::EvalOut* out, float* logits) {
+    constexpr int L = TILE_MLP;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4;
+    float* a1 = smem;                    // [L][ld]
+    float* a2 = smem + (size_t)L * ld;   // [L][ld]
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    const float* w1p1 = net.w1t + (size_t)(hw * 4) * H;
+    const float* w1p2 = net.w1t + (size_t)(hw * 5) * H;
+    const float* w1ch = net.w1t + (size_t)(hw * 6) * H;
+    const float* w1sc = net.w1t + (size_t)(hw * 7) * H;
+    for (int nn = tid; nn < H; nn += NTHREADS) {
+        float ws[6];
+        for (int s = 0; s < 6; ++s) ws[s] = w1sc[(size_t)s * H + nn];
+        for (int l = 0; l < L; ++l) {
+            const LeafFeat& f = feat[l];
+            float acc = net.cmaze[(size_t)f.maze_id * H + nn];
+            acc += w1p1[(size_t)f.p1 * H + nn];
+            acc += w1p2[(size_t)f.p2 * H + nn];
+            for (int wd = 0; wd < 4; ++wd) {
+                unsigned long long m = cheese[l][wd];
+                while (m) {
+                    const int c = __ffsll((long long)m) - 1 + 64 * wd;
+                    m &= m - 1;
+                    acc += w1ch[(size_t)c * H + nn];
+                }
+            }
+            for (int s = 0; s < 6; ++s) acc = fmaf(f.sc[s], ws[s], acc);
+            a1[(size_t)l * ld + nn] = fmaxf(acc, 0.0f);
+        }
+    }
+    __syncthreads();
+    for (int nn = tid; nn < H; nn += NTHREADS) {
+        float acc[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) acc[l] = net.b2[nn];
+        dense_acc<L>(net.w2t, H, H, nn, a1, ld, acc);
+#pragma unroll
+        for (int l = 0; l < L; ++l) a2[(size_t)l * ld + nn] = fmaxf(acc[l], 0.0f);
+    }
+    __syncthreads();
+    // heads: 12 dot products per leaf
+    float* hl = a1;  // reuse: [L][12]
+    for (int idx = tid; idx < L * 12; idx += NTHREADS) {
+        const int l = idx / 12, o = idx % 12;
+        const float* w = net.wh + (size_t)o * H;
+        float acc = net.bh[o];
+        for (int k = 0; k < H; ++k) acc = fmaf(w[k], a2[(size_t)l * ld + k], acc);
+        hl[l * 12 + o] = acc;
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float* h = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(h, o.p1);
+        softmax5(h + 5, o.p2);
+        o.v1 = softplusf(h[10]);
+        o.v2 = softplusf(h[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = h[k];
+    }
+}
+
+// ---- SymmetricMLP -----------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_symmetric(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                        uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                        ar::EvalOut* out, float* logits) {
+    constexpr int L = TILE_SYM;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4;
+    float* sh = smem;                        // shared encoding   [L][ld]
+    float* pe = sh + (size_t)L * ld;         // player encoding   [L][ld]
+    float* t1 = pe + (size_t)L * ld;         // trunk layer 1     [L][ld]
+    float* h0 = t1 + (size_t)L * ld;         // h1, then h2       [2][L][ld]
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    // shared encoder input = [maze hw*4 | cheese hw | progress]
+    const float* wch = net.w1t + (size_t)(hw * 4) * H;
+    const float* wpr = net.w1t + (size_t)(hw * 5) * H;
+    for (int nn = tid; nn < H; nn += NTHREADS) {
+        const float wprog = wpr[nn];
+        for (int l = 0; l < L; ++l) {
+            const LeafFeat& f = feat[l];
+            float acc = net.cmaze[(size_t)f.maze_id * H + nn];
+            for (int wd = 0; wd < 4; ++wd) {
+                unsigned long long m = cheese[l][wd];
+                while (m) {
+                    const int c = __ffsll((long long)m) - 1 + 64 * wd;
+                    m &= m - 1;
+                    acc += wch[(size_t)c * H + nn];
+                }
+            }
+            acc = fmaf(f.sc[1], wprog, acc);
+            sh[(size_t)l * ld + nn] = fmaxf(acc, 0.0f);
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) {
+        // player encoder input = [pos one-hot hw | mud | score]
+        for (int nn = tid; nn < H; nn += NTHREADS) {
+            const float wm = net.wpt[(size_t)hw * H + nn], wsco = net.wpt[(size_t)(hw + 1) * H + nn], bb = net.bp[nn];
+            for (int l = 0; l < L; ++l) {
+                const LeafFeat& f = feat[l];
+                float acc = bb + net.wpt[(size_t)(p == 0 ? f.p1 : f.p2) * H + nn];
+                acc = fmaf(f.sc[2 + p], wm, acc);
+                acc = fmaf(f.sc[4 + p], wsco, acc);
+                pe[(size_t)l * ld + nn] = fmaxf(acc, 0.0f);
+            }
+        }
+        __syncthreads();
+        for (int nn = tid; nn < H; nn += NTHREADS) {
+            float acc[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) acc[l] = net.b2[nn];
+            dense_acc<L>(net.w2t, H, H, nn, sh, ld, acc);
+            dense_acc<L>(net.w2t + (size_t)H * H, H, H, nn, pe, ld, acc);
+#pragma unroll
+            for (int l = 0; l < L; ++l) t1[(size_t)l * ld + nn] = fmaxf(acc[l], 0.0f);
+        }
+        __syncthreads();
+        float* hp = h0 + (size_t)p * L * ld;
+        for (int nn = tid; nn < H; nn += NTHREADS) {
+            float acc[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) acc[l] = net.b3[nn];
+            dense_acc<L>(net.w3t, H, H, nn, t1, ld, acc);
+#pragma unroll
+            for (int l = 0; l < L; ++l) hp[(size_t)l * ld + nn] = fmaxf(acc[l], 0.0f);
+        }
+        __syncthreads();
+    }
+    // heads on cat(h_i, h1 + h2): 6 rows (policy 5, value 1) x 2 players
+    float* hl = sh;  // reuse [L][12]
+    for (int idx = tid; idx < L * 12; idx += NTHREADS) {
+        const int l = idx / 12, r = idx % 12, p = r / 6, o = r % 6;
+        const float* w = net.wh + (size_t)o * (2 * H);
+        const float* hi = h0 + (size_t)p * L * ld + (size_t)l * ld;
+        const float* ha = h0 + (size_t)l * ld;
+        const float* hb = h0 + (size_t)L * ld + (size_t)l * ld;
+        float acc = net.bh[o];
+        for (int k = 0; k < H; ++k) acc = fmaf(w[k], hi[k], acc);
+        for (int k = 0; k < H; ++k) acc = fmaf(w[H + k], ha[k] + hb[k], acc);
+        hl[l * 12 + r] = acc;
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float* h = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(h, o.p1);
+        softmax5(h + 6, o.p2);
+        o.v1 = softplusf(h[5]);
+        o.v2 = softplusf(h[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 5; ++k) {
+                logits[(size_t)(base + tid) * 10 + k] = h[k];
+                logits[(size_t)(base + tid) * 10 + 5 + k] = h[6 + k];
+            }
+    }
+}
+
+// flat observation (flat_encoder.rs:52-125), one block per position
+template <int NW>
+__global__ void k_encode(const ar::LeafReq<NW>* q, uint32_t n, const ar::Board* boards, const uint8_t* maze_pool,
+                         float* obs, int obs_stride) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const ar::State<NW>& st = q[i].st;
+    const ar::Board& b = boards[q[i].slot];
+    const int hw = b.width * b.height;
+    const uint8_t* cost = maze_pool + b.maze_off;
+    float* o = obs + (size_t)i * obs_stride;
+    for (int k = threadIdx.x; k < hw * 4; k += blockDim.x) o[k] = cost[k] ? (float)cost[k] / 10.0f : -1.0f;
+    for (int k = threadIdx.x; k < hw; k += blockDim.x) {
+        o[hw * 4 + k] = k == st.p1 ? 1.0f : 0.0f;
+        o[hw * 5 + k] = k == st.p2 ? 1.0f : 0.0f;
+        o[hw * 6 + k] = ar::st_has_cheese(st, k) ? 1.0f : 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        float* s = o + hw * 7;
+        s[0] = st.s1 - st.s2;
+        s[1] = b.max_turns > 0 ? (float)st.turn / (float)b.max_turns : 0.0f;
+        s[2] = (float)st.m1 / 10.0f;
+        s[3] = (float)st.m2 / 10.0f;
+        s[4] = st.s1 / 10.0f;
+        s[5] = st.s2 / 10.0f;
+    }
+}
+
+}  // namespace arnet
+
+// ---- host object --------------------------------------------------------------------------------
+struct ArNet {
+    int device = 0;
+    arnet::NetDev dev;
+    std::vector<void*> allocs;
+    float* cmaze = nullptr;
+    const uint8_t* bound_pool = nullptr;
+    int bound_mazes = 0;
+    size_t smem = 0;
+
+    ~ArNet() {
+        for (void* p : allocs) hipFree(p);
+        if (cmaze) hipFree(cmaze);
+    }
+    const float* upload(const std::vector<float>& v, bool& ok) {
+        float* d = nullptr;
+        if (hipMalloc((void**)&d, v.size() * 4 + 16) != hipSuccess) {
+            ok = false;
+            return nullptr;
+        }
+        allocs.push_back(d);
+        if (hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return d;
+    }
+};
+
+static int net_build(const arnet::Blob& b, ArNet* net) {
+    using namespace arnet;
+    std::string err;
+    NetDev& d = net->dev;
+    memset(&d, 0, sizeof d);
+    d.arch = (int)b.arch;
+    d.width = (int)b.width;
+    d.height = (int)b.height;
+    d.hw = d.width * d.height;
+    bool ok = true;
+    std::vector<float> wt, bias;
+    uint32_t in = 0, out = 0;
+    if (b.arch == ARCH_MLP) {
+        if (!fold_linear(b, "trunk.0", "trunk.1", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        if ((int)in != d.hw * 7 + 6) return nets_fail(AR_E_BACKEND, "MLP input width does not match the board size");
+        d.H = (int)out;
+        d.w1t = net->upload(wt, ok);
+        d.b1 = net->upload(bias, ok);
+        if (!fold_linear(b, "trunk.4", "trunk.5", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        d.w2t = net->upload(wt, ok);
+        d.b2 = net->upload(bias, ok);
+        std::vector<float> wh((size_t)12 * d.H), bh(12);
+        const char* heads[3] = {"policy_p1_head", "policy_p2_head", "value_head"};
+        const int rows[3] = {5, 5, 2};
+        int r0 = 0;
+        for (int h = 0; h < 3; ++h) {
+            const std::vector<float>*w = b.get(std::string(heads[h]) + ".weight"), *bi = b.get(std::string(heads[h]) + ".bias");
+            if (!w || !bi || (int)w->size() != rows[h] * d.H) return nets_fail(AR_E_BACKEND, std::string("bad head ") + heads[h]);
+            memcpy(&wh[(size_t)r0 * d.H], w->data(), w->size() * 4);
+            memcpy(&bh[r0], bi->data(), bi->size() * 4);
+            r0 += rows[h];
+        }
+        d.wh = net->upload(wh, ok);
+        d.bh = net->upload(bh, ok);
+        d.n_head = 12;
+        d.Kh = d.H;
+        net->smem = (size_t)2 * TILE_MLP * (d.H + 4) * 4;
+    } else if (b.arch == ARCH_SYMMETRIC) {
+        if (!fold_linear(b, "shared_encoder.0", "shared_encoder.1", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        if ((int)in != d.hw * 5 + 1) return nets_fail(AR_E_BACKEND, "SymmetricMLP input width does not match the board size");
+        d.H = (int)out;
+        d.w1t = net->upload(wt, ok);
+        d.b1 = net->upload(bias, ok);
+        if (!fold_linear(b, "player_encoder.0", "player_encoder.1", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        d.wpt = net->upload(wt, ok);
+        d.bp = net->upload(bias, ok);
+        if (!fold_linear(b, "trunk.0", "trunk.1", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        d.w2t = net->upload(wt, ok);
+        d.b2 = net->upload(bias, ok);
+        if (!fold_linear(b, "trunk.4", "trunk.5", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
+        d.w3t = net->upload(wt, ok);
+        d.b3 = net->upload(bias, ok);
+        const std::vector<float>*pw = b.get("policy_head.weight"), *pb = b.get("policy_head.bias"),
+                          *vw = b.get("value_head.weight"), *vb = b.get("value_head.bias");
+        if (!pw || !pb || !vw || !vb) return nets_fail(AR_E_BACKEND, "weight blob lacks the symmetric heads");
+        std::vector<float> wh((size_t)6 * 2 * d.H), bh(6);
+        memcpy(wh.data(), pw->data(), pw->size() * 4);
+        memcpy(&wh[(size_t)5 * 2 * d.H], vw->data(), vw->size() * 4);
+        memcpy(bh.data(), pb->data(), 20);
+        bh[5] = (*vb)[0];
+        d.wh = net->upload(wh, ok);
+        d.bh = net->upload(bh, ok);
+        d.n_head = 6;
+        d.Kh = 2 * d.H;
+        net->smem = (size_t)5 * TILE_SYM * (d.H + 4) * 4;
+    } else {
+        return nets_fail(AR_E_BACKEND, "the CNN evaluator is not built in this revision (mlp and symmetric are)");
+    }
+    if (d.H % 4 != 0 || d.H > 1024) return nets_fail(AR_E_BACKEND, "hidden_dim must be a multiple of 4 and <= 1024");
+    if (!ok) return nets_fail(AR_E_NOMEM, "device allocation failed while loading weights");
+    if (net->smem > 160 * 1024) return nets_fail(AR_E_BACKEND, "hidden_dim too large for the LDS tile");
+    return AR_OK;
+}
+
+// per-maze first-layer constants for a pool of `n_mazes` cost tables of this net's board size
+static int net_bind_mazes(ArNet* net, const uint8_t* d_maze_pool, int n_mazes, hipStream_t stream) {
+    if (net->bound_pool == d_maze_pool && net->bound_mazes == n_mazes) return AR_OK;
+    if (net->cmaze) hipFree(net->cmaze);
+    net->cmaze = nullptr;
+    if (hipMalloc((void**)&net->cmaze, (size_t)n_mazes * net->dev.H * 4) != hipSuccess)
+        return nets_fail(AR_E_NOMEM, "device allocation failed (maze constants)");
+    hipLaunchKernelGGL(arnet::k_maze_const, dim3(n_mazes), dim3(256), 0, stream, net->dev.w1t, net->dev.b1, net->dev.H,
+                       net->dev.hw, d_maze_pool, n_mazes, net->cmaze);
+    if (hipGetLastError() != hipSuccess) return nets_fail(AR_E_DEVICE, "k_maze_const launch failed");
+    net->dev.cmaze = net->cmaze;
+    net->dev.n_mazes = n_mazes;
+    net->bound_pool = d_maze_pool;
+    net->bound_mazes = n_mazes;
+    return AR_OK;
+}
+
+template <int NW>
+static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcount, uint32_t n_max, const char* boards,
+                      size_t board_stride, ar::EvalOut* out, float* logits, hipStream_t stream) {
+    using namespace arnet;
+    if (n_max == 0) return AR_OK;
+    const int tile = net->dev.arch == ARCH_MLP ? TILE_MLP : TILE_SYM;
+    const uint32_t blocks = (n_max + tile - 1) / tile;
+    if (net->dev.arch == ARCH_MLP) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
+                           board_stride, out, logits);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_symmetric<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_symmetric<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max,
+                           boards, board_stride, out, logits);
+    }
+    if (hipGetLastError() != hipSuccess) return nets_fail(AR_E_DEVICE, "network kernel launch failed");
+    return AR_OK;
+}
+
+// evaluator step of the self-play loop: leaves in `queue[0 .. *queue_count)` -> ev_out
+template <int NW>
+static int net_forward_queue(ArNet* net, const ar::LeafReq<NW>* queue, const uint32_t* queue_count, uint32_t n_max,
+                             const ar::Slot<NW>* slots, const uint8_t* maze_pool, ar::EvalOut* ev_out,
+                             hipStream_t stream) {
+    (void)maze_pool;
+    return net_launch<NW>(net, queue, queue_count, n_max, (const char*)&slots[0].board, sizeof(ar::Slot<NW>), ev_out,
+                          nullptr, stream);
 }
