@@ -103,7 +103,10 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
                                                      const uint8_t* maze_pool, const ZigTables* zt, int iters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    Slot<NW>& s = slots[i];
+    if (slots[i].status != SLOT_ACTIVE) return;
+    // Work on a private copy of the slot header: its scalars (rng state, arena cursors, batch
+    // counters) then live in registers instead of being re-read from HBM after every store.
+    Slot<NW> s = slots[i];
     GatherCtx cx;
     cx.cost = maze_pool + s.board.maze_off;
     cx.eval_mode = EVAL_UNIFORM;
@@ -112,6 +115,7 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
         if (!gather_batch(s, cx, cfg)) break;
         if (backup_batch(s, cfg, s.ev_local, zt)) finish_move(s, cx.cost, cfg);
     }
+    slots[i] = s;
 }
 
 // Split form for evaluators that run outside the tree walk (networks, host callbacks).
@@ -120,13 +124,12 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
                                                const uint8_t* maze_pool, LeafReq<NW>* queue, uint32_t* queue_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    Slot<NW>& s = slots[i];
-    if (s.status != SLOT_ACTIVE) return;
+    if (slots[i].status != SLOT_ACTIVE) return;
+    Slot<NW> s = slots[i];
     GatherCtx cx;
     cx.cost = maze_pool + s.board.maze_off;
     cx.eval_mode = EVAL_STORE;
-    if (!gather_batch(s, cx, cfg)) return;
-    if (queue != nullptr && s.b_nn > 0) {
+    if (gather_batch(s, cx, cfg) && queue != nullptr && s.b_nn > 0) {
         const uint32_t base = atomicAdd(queue_count, s.b_nn);
         s.eval_base = base;
         for (uint32_t j = 0; j < s.b_nn; ++j) {
@@ -135,6 +138,7 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
             queue[base + j].pad = 0;
         }
     }
+    slots[i] = s;
 }
 
 template <int NW>
@@ -142,10 +146,11 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
                                                const uint8_t* maze_pool, const ZigTables* zt, const EvalOut* ev_queue) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    Slot<NW>& s = slots[i];
-    if (s.status != SLOT_ACTIVE || !s.batch_active) return;
+    if (slots[i].status != SLOT_ACTIVE || !slots[i].batch_active) return;
+    Slot<NW> s = slots[i];
     const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : s.ev_local;
     if (backup_batch(s, cfg, ev, zt)) finish_move(s, maze_pool + s.board.maze_off, cfg);
+    slots[i] = s;
 }
 
 // evaluator failure: revert the gathered batch (search.rs:919-955)

@@ -511,7 +511,7 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
     }
     if (d.H % 4 != 0 || d.H > 1024) return nets_fail(AR_E_BACKEND, "hidden_dim must be a multiple of 4 and <= 1024");
     if (!ok) return nets_fail(AR_E_NOMEM, "device allocation failed while loading weights");
-    if (net->smem > 160 * 1024) return nets_fail(AR_E_BACKEND, "hidden_dim too large for the LDS tile");
+    if (net->smem > 150 * 1024) return nets_fail(AR_E_BACKEND, "hidden_dim too large for the LDS tile");
     return AR_OK;
 }
 
@@ -540,23 +540,22 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     const int tile = net->dev.arch == ARCH_MLP ? TILE_MLP : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_MLP) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        if (net->smem > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) !=
+                hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
         hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)k_symmetric<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric<NW>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)net->smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
         hipLaunchKernelGGL(k_symmetric<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max,
                            boards, board_stride, out, logits);
     }
-    if (hipGetLastError() != hipSuccess) return nets_fail(AR_E_DEVICE, "network kernel launch failed");
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return nets_fail(AR_E_DEVICE, std::string("network kernel launch failed: ") + hipGetErrorString(le));
     return AR_OK;
 }
 
