@@ -100,8 +100,10 @@ __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t
 // SmartUniform is evaluated inside the gather, so the whole simulate_batch is one pass.
 template <int NW>
 __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
-                                                     const uint8_t* maze_pool, const ZigTables* zt, int iters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                     const uint8_t* maze_pool, const ZigTables* zt, int iters,
+                                                     uint32_t lanes) {
+    if (threadIdx.x >= lanes) return;
+    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE) return;
     // Work on a private copy of the slot header: its scalars (rng state, arena cursors, batch
@@ -562,8 +564,9 @@ struct Engine {
         HIP_TRY(hipEventRecord(ev0, stream));
         for (int k = 0; k < n_launch; ++k) {
             if (net == nullptr) {
-                hipLaunchKernelGGL(k_step_uniform<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p,
-                                   zig.p, iters);
+                static const uint32_t lanes = getenv("AR_LANES_PER_WAVE") ? (uint32_t)atoi(getenv("AR_LANES_PER_WAVE")) : 64u;
+                hipLaunchKernelGGL(k_step_uniform<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg,
+                                   maze.p, zig.p, iters, lanes);
                 steps += (uint64_t)iters;
             } else {
                 for (int it = 0; it < iters; ++it) {
@@ -1185,6 +1188,14 @@ int ar_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return fail(AR_E_DEVICE, "hipGetDeviceCount failed (no HIP device?)");
     return n;
+}
+
+int ar_device_sync(int device) {
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipDeviceSynchronize());
+    return AR_OK;
 }
 
 int ar_search_many(const ArGameSpec* games, uint32_t n, const ArSearchConfig* cfg, uint32_t simulations,

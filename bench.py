@@ -130,12 +130,15 @@ def main() -> int:
     for w in range(args.warmup):
         one_step(-1 - w)
 
-    import torch
+    from alpharat_amd import _lib
 
     def sync():
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        # device-wide sync through the library (hipDeviceSynchronize) + torch's too when it is loaded
+        _lib.check(_lib.load().ar_device_sync(local_rank))
         if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
             dist.barrier()
 
     sync()
@@ -152,6 +155,8 @@ def main() -> int:
                nv=stats.gather_node_visits + stats.backup_node_visits, new=stats.new_nodes)
     tree_secs, net_secs, dev_steps = stats.device_secs, 0.0, stats.steps
     if dist is not None:
+        import torch
+
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

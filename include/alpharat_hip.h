@@ -89,6 +89,8 @@ const char* ar_version(void);
 size_t ar_last_error(char* buf, size_t cap);
 /* number of visible HIP devices, or AR_E_DEVICE */
 int ar_device_count(void);
+/* hipDeviceSynchronize on `device` (benchmark bracketing) */
+int ar_device_sync(int device);
 
 /* ---- evaluator: replaces OnnxBackend / TensorrtBackend (+ FlatEncoder) -----------------------
  * crates/alpharat-sampling/src/backends/onnx.rs:176-246, tensorrt.rs:423 ff., trt_shim.cpp:53-324.
