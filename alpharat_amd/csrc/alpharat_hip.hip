@@ -69,125 +69,220 @@ struct DoneInfo {
     MoveResult last;
 };
 
-struct ArenaPool {
-    NodeStats* stats;
-    NodeKids* kids;
-    uint32_t cap0;
+// the three bases every tree kernel receives; all per-game addresses derive from them
+struct Bases {
+    unsigned char* arena;    // pool of first arenas; grown arenas are addressed relative to it too
+    unsigned char* scratch;  // S x layout.total
+    const uint8_t* maze;     // cost tables
+    SlotLayout L;
+    uint32_t cap0;           // nodes per first arena
 };
 
 template <int NW>
-__global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, unsigned char* scratch,
-                             SlotLayout L, ArenaPool pool, const uint8_t* maze_pool, SearchCfg cfg) {
+__global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, Bases B, SearchCfg cfg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const GameInit<NW>& gi = init[i];
-    Slot<NW>& s = slots[gi.slot];
-    if (s.stats == nullptr) {
-        s.stats = pool.stats + (size_t)gi.slot * pool.cap0;
-        s.kids = pool.kids + (size_t)gi.slot * pool.cap0;
-        s.cap = pool.cap0;
+    const GameInit<NW> gi = init[i];
+    Slot<NW> s = slots[gi.slot];
+    if (s.cap == 0) {  // first use of this slot: its share of the arena pool
+        const long long base = (long long)gi.slot * (long long)arena_bytes(B.cap0);
+        s.cap = B.cap0;
+        s.stats_off = base;
+        s.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
+        s.fwd_off = s.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
     }
-    bind_scratch(s, scratch + (size_t)gi.slot * L.total, L);
     s.board = gi.board;
     s.st = gi.st;
     rng_seed(s.rng, gi.rng_seed);
     s.game_index = gi.game_index;
     s.single_search = gi.single;
-    start_game(s, maze_pool + gi.board.maze_off, cfg);
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, gi.slot, B.L, B.maze);
+    start_game(s, m, cfg);
+    slots[gi.slot] = s;
 }
 
-// One thread walks one game's tree: `iters` x (gather -> evaluate -> backup [-> end of turn]).
-// SmartUniform is evaluated inside the gather, so the whole simulate_batch is one pass.
+// One lane walks one game's tree: `iters` x (gather -> evaluate -> backup [-> end of turn]).
+// SmartUniform is evaluated inside the gather, so the whole simulate_batch is one pass. The slot
+// header is copied to registers for the duration of the kernel.
 template <int NW>
-__global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
-                                                     const uint8_t* maze_pool, const ZigTables* zt, int iters,
-                                                     uint32_t lanes) {
-    if (threadIdx.x >= lanes) return;
-    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
+__global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                                     const ZigTables* zt, int iters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE) return;
-    // Work on a private copy of the slot header: its scalars (rng state, arena cursors, batch
-    // counters) then live in registers instead of being re-read from HBM after every store.
     Slot<NW> s = slots[i];
-    GatherCtx cx;
-    cx.cost = maze_pool + s.board.maze_off;
-    cx.eval_mode = EVAL_UNIFORM;
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
     for (int it = 0; it < iters; ++it) {
         if (s.status != SLOT_ACTIVE) break;
-        if (!gather_batch(s, cx, cfg)) break;
-        if (backup_batch(s, cfg, s.ev_local, zt)) finish_move(s, cx.cost, cfg);
+        if (!gather_machine(s, m, cfg, EVAL_UNIFORM)) break;
+        if (backup_machine(s, m, cfg, m.ev_local, zt)) finish_move(s, m, cfg);
     }
     slots[i] = s;
 }
 
 // Split form for evaluators that run outside the tree walk (networks, host callbacks).
 template <int NW>
-__global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
-                                               const uint8_t* maze_pool, LeafReq<NW>* queue, uint32_t* queue_count) {
+__global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                               LeafReq<NW>* queue, uint32_t* queue_count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE) return;
     Slot<NW> s = slots[i];
-    GatherCtx cx;
-    cx.cost = maze_pool + s.board.maze_off;
-    cx.eval_mode = EVAL_STORE;
-    if (gather_batch(s, cx, cfg) && queue != nullptr && s.b_nn > 0) {
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    if (gather_machine(s, m, cfg, EVAL_STORE) && queue != nullptr && s.b_nn > 0) {
         const uint32_t base = atomicAdd(queue_count, s.b_nn);
         s.eval_base = base;
         for (uint32_t j = 0; j < s.b_nn; ++j) {
-            queue[base + j].st = s.leaf_local[j];
-            queue[base + j].slot = i;
-            queue[base + j].pad = 0;
+            LeafReq<NW> r;
+            r.st = m.leaf_local[j];
+            r.slot = i;
+            r.pad = 0;
+            queue[base + j] = r;
         }
     }
     slots[i] = s;
 }
 
 template <int NW>
-__global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg,
-                                               const uint8_t* maze_pool, const ZigTables* zt, const EvalOut* ev_queue) {
+__global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                               const ZigTables* zt, const EvalOut* ev_queue) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE || !slots[i].batch_active) return;
     Slot<NW> s = slots[i];
-    const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : s.ev_local;
-    if (backup_batch(s, cfg, ev, zt)) finish_move(s, maze_pool + s.board.maze_off, cfg);
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : m.ev_local;
+    if (backup_machine(s, m, cfg, ev, zt)) finish_move(s, m, cfg);
     slots[i] = s;
+}
+
+// Tree reuse (tree.rs:283-302): one wavefront per game re-roots the tree by the in-place sliding
+// compaction described in dev_search.h (advance_tree_scalar is the one-lane statement of the same
+// passes). Pass 1 decides keep/drop and new ids 64 nodes at a time (parents inside the same 64 are
+// resolved by lane shuffles, the running count by ballot + popcount); pass 2 moves kept nodes.
+template <int NW>
+__global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B) {
+    const uint32_t slot = blockIdx.x;
+    if (slot >= n_slots) return;
+    if (slots[slot].status != SLOT_ADVANCE) return;
+    const uint32_t lane = threadIdx.x;
+    Slot<NW> s = slots[slot];
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
+    const uint32_t keep_root = s.pending_root;
+    if (keep_root == NIL) {
+        if (lane == 0) {
+            make_root(s, m);
+            s.status = SLOT_ACTIVE;
+            slots[slot] = s;
+        }
+        return;
+    }
+    const uint32_t hi = s.hi;
+    uint32_t cnt = 0;
+    const uint32_t first = keep_root & ~63u;
+    for (uint32_t base = 0; base < first; base += 64) {  // everything before the kept root is dropped
+        const uint32_t i = base + lane;
+        if (i < hi) __hip_atomic_store(&m.fwd[i], NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (uint32_t base = first; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        // 0 unknown, 1 keep, 2 drop
+        uint32_t st = 2, p = NIL;
+        if (i < hi) {
+            if (i == keep_root) st = 1;
+            else if (i > keep_root) {
+                p = m.stats[i].h1.parent;
+                if (p == NIL) st = 2;
+                else if (p < base)
+                    st = __hip_atomic_load(&m.fwd[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NIL ? 1u : 2u;
+                else st = 0;
+            }
+        }
+        // parents inside this group of 64: propagate along the id order (parent lane < child lane)
+        for (int round = 0; round < 64; ++round) {
+            const uint32_t src = (st == 0) ? (p - base) : lane;
+            const uint32_t pst = (uint32_t)__shfl((int)st, (int)src, 64);
+            if (st == 0 && pst != 0) st = pst;
+            if (!__any(st == 0)) break;
+        }
+        const bool keep = st == 1;
+        const unsigned long long bal = __ballot(keep);
+        const uint32_t before = (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+        if (i < hi)
+            __hip_atomic_store(&m.fwd[i], keep ? cnt + before : NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cnt += (uint32_t)__popcll(bal);
+    }
+    __threadfence();  // all new ids are in L2 before any lane reads another lane's
+    __syncthreads();
+    for (uint32_t base = first; base < hi; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t ni = NIL;
+        if (i < hi) ni = __hip_atomic_load(&m.fwd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        NodeStats nd;
+        NodeKids kd;
+        if (ni != NIL) {
+            nd = m.stats[i];
+            kd = m.kids[i];
+            nd.h1.parent = i == keep_root ? NIL
+                                          : __hip_atomic_load(&m.fwd[nd.h1.parent], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+            for (int c = 0; c < 25; ++c)
+                if (kd.c[c] != NIL)
+                    kd.c[c] = __hip_atomic_load(&m.fwd[kd.c[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // every lane has read its node before any lane overwrites a source
+        if (ni != NIL) {
+            m.stats[ni] = nd;
+            m.kids[ni] = kd;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        s.root = 0;
+        s.hi = cnt;
+        s.node_count = cnt;
+        s.status = SLOT_ACTIVE;
+        slots[slot] = s;
+    }
 }
 
 // evaluator failure: revert the gathered batch (search.rs:919-955)
 template <int NW>
-__global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots) {
+__global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots, Bases B) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    Slot<NW>& s = slots[i];
-    if (s.batch_active) cancel_batch(s);
+    Slot<NW> s = slots[i];
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    if (s.batch_active) cancel_batch(s, m);
     if (s.status == SLOT_ACTIVE) s.status = SLOT_FAILED;
+    slots[i] = s;
 }
 
-// counts[0] done, [1] stalled, [2] active, [3] errors; lists hold slot ids
+// counts[0] done, [1] stalled, [2] active (incl. waiting for k_advance), [3] errors; lists hold slot ids
 template <int NW>
 __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts, uint32_t* done_list,
                        uint32_t* stall_list) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    const Slot<NW>& s = slots[i];
-    if (s.error) atomicAdd(&counts[3], 1u);
-    if (s.status == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
-    else if (s.status == SLOT_STALL) stall_list[atomicAdd(&counts[1], 1u)] = i;
-    else if (s.status == SLOT_ACTIVE) atomicAdd(&counts[2], 1u);
+    const uint32_t st = slots[i].status;
+    if (slots[i].error) atomicAdd(&counts[3], 1u);
+    if (st == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
+    else if (st == SLOT_STALL) stall_list[atomicAdd(&counts[1], 1u)] = i;
+    else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE) atomicAdd(&counts[2], 1u);
 }
 
 // one block per finished game: header by thread 0, position records copied by the whole block
 template <int NW>
 __global__ void k_pack_done(Slot<NW>* slots, const uint32_t* done_list, uint32_t n_done, DoneInfo<NW>* info,
-                            PosRec<NW>* staging, uint32_t max_turns) {
+                            PosRec<NW>* staging, uint32_t max_turns, Bases B) {
     const uint32_t d = blockIdx.x;
     if (d >= n_done) return;
-    Slot<NW>& s = slots[done_list[d]];
+    const uint32_t slot = done_list[d];
+    Slot<NW>& s = slots[slot];
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
     if (threadIdx.x == 0) {
         DoneInfo<NW>& o = info[d];
-        o.slot = done_list[d];
+        o.slot = slot;
         o.game_index = s.game_index;
         o.n_pos = s.n_pos;
         o.error = s.error;
@@ -203,46 +298,60 @@ __global__ void k_pack_done(Slot<NW>* slots, const uint32_t* done_list, uint32_t
     }
     const uint32_t n = s.n_pos < max_turns ? s.n_pos : max_turns;
     const uint32_t words = n * (uint32_t)(sizeof(PosRec<NW>) / 4);
-    const uint32_t* src = (const uint32_t*)s.pos;
+    const uint32_t* src = (const uint32_t*)m.pos;
     uint32_t* dst = (uint32_t*)(staging + (size_t)d * max_turns);
     for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
     __syncthreads();
     if (threadIdx.x == 0) s.status = SLOT_EMPTY;
 }
 
+// arena growth: what a stalled slot reports, and its new home once the host has copied the nodes
+struct StallInfo {
+    uint32_t slot, cap, hi, need;
+    long long stats_off, kids_off;
+};
 struct GrowReq {
-    uint32_t slot;
-    uint32_t cap;
-    NodeStats* stats;
-    NodeKids* kids;
+    uint32_t slot, cap;
+    long long stats_off, kids_off, fwd_off;
 };
 template <int NW>
-__global__ void k_migrate(Slot<NW>* slots, const GrowReq* req, uint32_t n) {
+__global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, uint32_t n, StallInfo* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    migrate_slot(slots[req[i].slot], req[i].stats, req[i].kids, req[i].cap);
+    const Slot<NW>& s = slots[stall_list[i]];
+    StallInfo o;
+    o.slot = stall_list[i];
+    o.cap = s.cap;
+    o.hi = s.hi;
+    o.need = s.need_nodes;
+    o.stats_off = s.stats_off;
+    o.kids_off = s.kids_off;
+    out[i] = o;
 }
-
 template <int NW>
-__global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, uint32_t n, uint32_t* need,
-                             uint32_t* cap) {
+__global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    need[i] = slots[stall_list[i]].need_nodes;
-    cap[i] = slots[stall_list[i]].cap;
+    Slot<NW>& s = slots[req[i].slot];
+    s.cap = req[i].cap;
+    s.stats_off = req[i].stats_off;
+    s.kids_off = req[i].kids_off;
+    s.fwd_off = req[i].fwd_off;
+    s.status = SLOT_ACTIVE;
 }
 
 // host-callback evaluator support: leaves out, results in (single-slot searches)
 template <int NW>
-__global__ void k_export_leaves(const Slot<NW>* slots, uint32_t slot, State<NW>* out, uint32_t* n_out) {
+__global__ void k_export_leaves(const Slot<NW>* slots, uint32_t slot, Bases B, State<NW>* out, uint32_t* n_out) {
     const Slot<NW>& s = slots[slot];
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
     if (threadIdx.x == 0) *n_out = s.batch_active ? s.b_nn : 0;
-    for (uint32_t j = threadIdx.x; j < s.b_nn; j += blockDim.x) out[j] = s.leaf_local[j];
+    for (uint32_t j = threadIdx.x; j < s.b_nn; j += blockDim.x) out[j] = m.leaf_local[j];
 }
 template <int NW>
-__global__ void k_import_evals(Slot<NW>* slots, uint32_t slot, const EvalOut* in, uint32_t n) {
-    Slot<NW>& s = slots[slot];
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) s.ev_local[j] = in[j];
+__global__ void k_import_evals(const Slot<NW>* slots, uint32_t slot, Bases B, const EvalOut* in, uint32_t n) {
+    const Mem<NW> m = resolve_mem<NW>(slots[slot], B.arena, B.scratch, slot, B.L, B.maze);
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) m.ev_local[j] = in[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,11 +572,11 @@ struct Engine {
     uint32_t max_turns = 0, cap0 = 0;
     DevBuf<Slot<NW>> slots;
     DevBuf<unsigned char> scratch;
-    DevBuf<NodeStats> stats;
-    DevBuf<NodeKids> kids;
+    DevBuf<unsigned char> arena;
     DevBuf<uint8_t> maze;
     DevBuf<ZigTables> zig;
-    DevBuf<uint32_t> counts, done_list, stall_list, need, capv;
+    DevBuf<uint32_t> counts, done_list, stall_list;
+    DevBuf<StallInfo> stall_info;
     DevBuf<GameInit<NW>> init;
     DevBuf<DoneInfo<NW>> info;
     DevBuf<PosRec<NW>> staging;
@@ -475,7 +584,8 @@ struct Engine {
     DevBuf<LeafReq<NW>> queue;
     DevBuf<EvalOut> ev_queue;
     DevBuf<uint32_t> queue_count;
-    PinBuf<uint32_t> h_counts, h_done, h_stall, h_need, h_cap;
+    PinBuf<uint32_t> h_counts;
+    PinBuf<StallInfo> h_stall;
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
     std::vector<void*> grown;  // arenas allocated after a stall, freed with the engine
@@ -487,10 +597,21 @@ struct Engine {
     ArNet* net = nullptr;
 
     ~Engine() {
+        if (stream) hipStreamSynchronize(stream);
         for (void* p : grown) hipFree(p);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (stream) hipStreamDestroy(stream);
+    }
+
+    Bases bases() const {
+        Bases b;
+        b.arena = arena.p;
+        b.scratch = scratch.p;
+        b.maze = maze.p;
+        b.L = L;
+        b.cap0 = cap0;
+        return b;
     }
 
     int setup(int device, uint32_t n_slots, const SearchCfg& c, uint32_t mt, const std::vector<uint8_t>& maze_bytes,
@@ -508,8 +629,7 @@ struct Engine {
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
-        HIP_TRY(stats.alloc((size_t)S * cap0));
-        HIP_TRY(kids.alloc((size_t)S * cap0));
+        HIP_TRY(arena.alloc((size_t)S * arena_bytes(cap0) + 256));
         HIP_TRY(maze.alloc(maze_bytes.size()));
         HIP_TRY(hipMemcpyAsync(maze.p, maze_bytes.data(), maze_bytes.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(zig.alloc(1));
@@ -518,17 +638,13 @@ struct Engine {
         HIP_TRY(counts.alloc(4));
         HIP_TRY(done_list.alloc(S));
         HIP_TRY(stall_list.alloc(S));
-        HIP_TRY(need.alloc(S));
-        HIP_TRY(capv.alloc(S));
+        HIP_TRY(stall_info.alloc(S));
         HIP_TRY(init.alloc(S));
         HIP_TRY(info.alloc(S));
         HIP_TRY(staging.alloc((size_t)S * max_turns));
         HIP_TRY(grow.alloc(S));
         HIP_TRY(h_counts.alloc(4));
-        HIP_TRY(h_done.alloc(S));
         HIP_TRY(h_stall.alloc(S));
-        HIP_TRY(h_need.alloc(S));
-        HIP_TRY(h_cap.alloc(S));
         HIP_TRY(h_info.alloc(S));
         HIP_TRY(h_staging.alloc((size_t)S * max_turns));
         if (need_queue) {
@@ -550,34 +666,44 @@ struct Engine {
     int start_games(const std::vector<GameInit<NW>>& games) {
         if (games.empty()) return AR_OK;
         HIP_TRY(hipMemcpyAsync(init.p, games.data(), sizeof(GameInit<NW>) * games.size(), hipMemcpyHostToDevice, stream));
-        ArenaPool pool{stats.p, kids.p, cap0};
         hipLaunchKernelGGL(k_init_games<NW>, dim3(grid((uint32_t)games.size())), dim3(64), 0, stream, slots.p, init.p,
-                           (uint32_t)games.size(), scratch.p, L, pool, maze.p, cfg);
+                           (uint32_t)games.size(), bases(), cfg);
         HIP_TRY(hipGetLastError());
         // init.p is reused by the next call: wait for the copy + kernel
         HIP_TRY(hipStreamSynchronize(stream));
         return AR_OK;
     }
 
-    // `n_launch` kernel steps of `iters` simulate_batch each, timed with HIP events on our stream
+    void launch_gather(bool to_queue) {
+        hipLaunchKernelGGL(k_gather<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(),
+                           to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr);
+    }
+    void launch_backup(bool from_queue) {
+        hipLaunchKernelGGL(k_backup<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
+                           from_queue ? ev_queue.p : (const EvalOut*)nullptr);
+    }
+    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases()); }
+    void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
+
+    // `n_launch` rounds of {`iters` simulate_batch per game, then tree reuse for the games that moved},
+    // timed with HIP events on our stream
     int run_steps(int n_launch, int iters) {
         HIP_TRY(hipEventRecord(ev0, stream));
         for (int k = 0; k < n_launch; ++k) {
             if (net == nullptr) {
-                static const uint32_t lanes = getenv("AR_LANES_PER_WAVE") ? (uint32_t)atoi(getenv("AR_LANES_PER_WAVE")) : 64u;
-                hipLaunchKernelGGL(k_step_uniform<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg,
-                                   maze.p, zig.p, iters, lanes);
+                hipLaunchKernelGGL(k_step_uniform<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
+                                   iters);
+                launch_advance();
                 steps += (uint64_t)iters;
             } else {
                 for (int it = 0; it < iters; ++it) {
                     HIP_TRY(hipMemsetAsync(queue_count.p, 0, 4, stream));
-                    hipLaunchKernelGGL(k_gather<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p,
-                                       queue.p, queue_count.p);
+                    launch_gather(true);
                     int rc = net_forward_queue<NW>(net, queue.p, queue_count.p, (uint32_t)((size_t)S * cfg.batch_size),
                                                    slots.p, maze.p, ev_queue.p, stream);
                     if (rc != AR_OK) return rc;
-                    hipLaunchKernelGGL(k_backup<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, maze.p, zig.p,
-                                       ev_queue.p);
+                    launch_backup(true);
+                    launch_advance();
                     steps += 1;
                 }
             }
@@ -605,31 +731,38 @@ struct Engine {
         return AR_OK;
     }
 
+    // stalled games get a doubled arena: live nodes are copied across unchanged (ids are arena-relative)
     int handle_stalls(uint32_t n_stall) {
         if (n_stall == 0) return AR_OK;
         hipLaunchKernelGGL(k_read_stall<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, stall_list.p, n_stall,
-                           need.p, capv.p);
+                           stall_info.p);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_stall.p, stall_list.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_need.p, need.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_cap.p, capv.p, 4 * n_stall, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_stall.p, stall_info.p, sizeof(StallInfo) * n_stall, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         std::vector<GrowReq> reqs(n_stall);
         for (uint32_t i = 0; i < n_stall; ++i) {
-            uint32_t ncap = h_cap.p[i] * 2;
-            while (ncap < h_need.p[i]) ncap *= 2;
-            NodeStats* ns = nullptr;
-            NodeKids* nk = nullptr;
-            if (hipMalloc((void**)&ns, sizeof(NodeStats) * (size_t)ncap) != hipSuccess ||
-                hipMalloc((void**)&nk, sizeof(NodeKids) * (size_t)ncap) != hipSuccess)
+            const StallInfo& si = h_stall.p[i];
+            uint32_t ncap = si.cap * 2;
+            while (ncap < si.need) ncap *= 2;
+            unsigned char* na = nullptr;
+            if (hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess)
                 return fail(AR_E_NOMEM, "out of device memory while growing a tree arena to " + std::to_string(ncap) +
                                             " nodes");
-            grown.push_back(ns);
-            grown.push_back(nk);
-            reqs[i] = GrowReq{h_stall.p[i], ncap, ns, nk};
+            grown.push_back(na);
+            GrowReq r;
+            r.slot = si.slot;
+            r.cap = ncap;
+            r.stats_off = (long long)(na - arena.p);
+            r.kids_off = r.stats_off + (long long)ncap * (long long)sizeof(NodeStats);
+            r.fwd_off = r.kids_off + (long long)ncap * (long long)sizeof(NodeKids);
+            HIP_TRY(hipMemcpyAsync(na, arena.p + si.stats_off, (size_t)si.hi * sizeof(NodeStats), hipMemcpyDeviceToDevice,
+                                   stream));
+            HIP_TRY(hipMemcpyAsync(na + (size_t)ncap * sizeof(NodeStats), arena.p + si.kids_off,
+                                   (size_t)si.hi * sizeof(NodeKids), hipMemcpyDeviceToDevice, stream));
+            reqs[i] = r;
         }
         HIP_TRY(hipMemcpyAsync(grow.p, reqs.data(), sizeof(GrowReq) * n_stall, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_migrate<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall);
+        hipLaunchKernelGGL(k_apply_grow<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         grows += n_stall;
@@ -640,7 +773,7 @@ struct Engine {
     int drain(uint32_t n_done) {
         if (n_done == 0) return AR_OK;
         hipLaunchKernelGGL(k_pack_done<NW>, dim3(n_done), dim3(128), 0, stream, slots.p, done_list.p, n_done, info.p,
-                           staging.p, max_turns);
+                           staging.p, max_turns, bases());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_info.p, info.p, sizeof(DoneInfo<NW>) * n_done, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(h_staging.p, staging.p, sizeof(PosRec<NW>) * (size_t)n_done * max_turns,
@@ -650,7 +783,6 @@ struct Engine {
     }
 };
 
-// maze[y][x][dir] as the recorder stores it (selfplay.rs:374-392)
 std::vector<int8_t> maze_array(const std::vector<uint8_t>& cost) {
     std::vector<int8_t> m(cost.size());
     for (size_t i = 0; i < cost.size(); ++i) m[i] = cost[i] ? (int8_t)cost[i] : (int8_t)-1;
@@ -1104,9 +1236,9 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
                 continue;
             }
             if (c[2] == 0) break;
-            hipLaunchKernelGGL(k_gather<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u, cfg, eng.maze.p,
-                               (LeafReq<NW>*)nullptr, (uint32_t*)nullptr);
-            hipLaunchKernelGGL(k_export_leaves<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, d_leaves.p, d_n.p);
+            eng.launch_gather(false);
+            hipLaunchKernelGGL(k_export_leaves<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, eng.bases(),
+                               d_leaves.p, d_n.p);
             uint32_t nl = 0;
             HIP_TRY(hipMemcpyAsync(&nl, d_n.p, 4, hipMemcpyDeviceToHost, eng.stream));
             HIP_TRY(hipMemcpyAsync(leaves.data(), d_leaves.p, sizeof(State<NW>) * cfg.batch_size, hipMemcpyDeviceToHost,
@@ -1129,7 +1261,7 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
                     for (int k = 0; k < NW; ++k) a.cheese_bits[k] = s.cheese[k];
                 }
                 if (predict_fn(user, al.data(), nl, pp1.data(), pp2.data(), pv1.data(), pv2.data()) != 0) {
-                    hipLaunchKernelGGL(k_cancel<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u);
+                    eng.launch_cancel();
                     hipStreamSynchronize(eng.stream);
                     return fail(AR_E_BACKEND, "predict_fn raised an exception");
                 }
@@ -1140,10 +1272,10 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
                     ev[j].v2 = pv2[j];
                 }
                 HIP_TRY(hipMemcpyAsync(d_ev.p, ev.data(), sizeof(EvalOut) * nl, hipMemcpyHostToDevice, eng.stream));
-                hipLaunchKernelGGL(k_import_evals<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, d_ev.p, nl);
+                hipLaunchKernelGGL(k_import_evals<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 0u, eng.bases(),
+                                   d_ev.p, nl);
             }
-            hipLaunchKernelGGL(k_backup<NW>, dim3(1), dim3(64), 0, eng.stream, eng.slots.p, 1u, cfg, eng.maze.p,
-                               eng.zig.p, (const EvalOut*)nullptr);
+            eng.launch_backup(false);
             HIP_TRY(hipGetLastError());
         }
     } else {

@@ -3,14 +3,22 @@
 // crates/alpharat-sampling/src/selfplay.rs:515-598.
 //
 // Layout (one arena per game, all in HBM):
-//   NodeStats  256 B / node, 16-B edge records {prior, q, visits, in_flight} x 5 outcomes x 2
-//              players, then the node header. Everything select and backup touch is in these two
-//              128-B lines.
+//   NodeStats  256 B / node = sixteen 16-B groups: ten edge records {prior, q, visits, in_flight}
+//              ([player][outcome]) and three header groups. Every access below is a whole 16-B
+//              group, so a lane moves a node with dwordx4 loads/stores.
 //   NodeKids   128 B / node, a 25-slot child table indexed by (p1_outcome*5 + p2_outcome)
 //              (replaces the reference's linked list + find_child walk, tree.rs:52-63).
-// Node ids are arena indices; the live tree occupies [lo, hi) and new nodes bump `hi`. Moving the
-// root (tree reuse, tree.rs:283-295) copies the kept subtree in DFS order into the free part of
-// the same arena, which also yields the recounted node_count the collision budget depends on.
+// Node ids are arena indices; the live tree is [0, hi) and new nodes bump `hi`, so a parent's id is
+// always smaller than its children's. Moving the root (tree reuse, tree.rs:283-295) is an in-place
+// sliding compaction in id order done by a whole wavefront (advance_tree_*), which also yields the
+// recounted node_count the collision budget depends on.
+//
+// One lane walks one game. The reference's nested loops (allocation loop inside the DFS inside the
+// gather loop, then the backup walks) are flattened into one loop over small states
+// (gather_machine / backup_machine) so the 64 lanes of a wavefront, each at a different place of a
+// different tree, execute the same instructions most of the time. The per-node allocation state
+// (scores, started counts, the 25 visit allocations) lives in registers; it is spilled to the
+// per-game level stack only while a deeper level is being processed.
 //
 // All arithmetic keeps the reference's f32 operation order; build with -ffp-contract=off.
 #pragma once
@@ -20,31 +28,41 @@ namespace ar {
 
 static const uint32_t NIL = 0xFFFFFFFFu;
 
-struct Edge {
+struct alignas(16) Edge {
     float prior;
     float q;
     uint32_t visits;
     uint32_t nif;  // n_in_flight (virtual loss)
 };
-
+struct alignas(16) NodeH0 {
+    float v1, v2;     // Welford means
+    uint32_t visits;  // total_visits
+    uint32_t nif;     // n_in_flight
+};
+struct alignas(16) NodeH1 {
+    float scale;      // value_scale = max(remaining_cheese, 1) at creation
+    float r1, r2;     // edge rewards from the parent
+    uint32_t parent;  // NIL for the root
+};
+struct alignas(16) NodeH2 {
+    uint32_t omap[2];  // per player: outcome->action 3 bits each (bits 0..14), action->outcome (bits 15..29)
+    uint32_t meta;     // n_outcomes p1 | p2 << 8 | parent_outcome p1 << 16 | p2 << 24
+    uint32_t terminal;
+};
 struct alignas(128) NodeStats {
-    Edge e[2][5];        // [player][outcome]                     160 B
-    float v1, v2;        // Welford means
-    uint32_t visits;     // total_visits
-    uint32_t nif;        // n_in_flight
-    float scale;         // value_scale = max(remaining_cheese, 1) at creation
-    float r1, r2;        // edge rewards from the parent
-    uint32_t parent;     // NIL for the root
-    uint32_t omap[2];    // per player: outcome->action 3 bits each (bits 0..14), action->outcome (bits 15..29)
-    uint8_t n[2];        // n_outcomes
-    uint8_t po[2];       // parent_outcome
-    uint32_t terminal;   // is_terminal
+    Edge e[2][5];
+    NodeH0 h0;
+    NodeH1 h1;
+    NodeH2 h2;
     uint32_t pad[12];
 };
 struct alignas(128) NodeKids {
     uint32_t c[25];
     uint32_t pad[7];
 };
+
+AR_HD uint32_t meta_n(uint32_t meta, int pl) { return (meta >> (8 * pl)) & 0xffu; }
+AR_HD uint32_t meta_po(uint32_t meta, int pl) { return (meta >> (16 + 8 * pl)) & 0xffu; }
 
 struct SearchCfg {
     float c_puct, fpu_reduction, force_k, noise_epsilon, noise_concentration;
@@ -53,7 +71,7 @@ struct SearchCfg {
     uint32_t n_sims, batch_size;
 };
 
-enum { SLOT_EMPTY = 0, SLOT_ACTIVE = 1, SLOT_DONE = 2, SLOT_STALL = 3, SLOT_FAILED = 4 };
+enum { SLOT_EMPTY = 0, SLOT_ACTIVE = 1, SLOT_DONE = 2, SLOT_STALL = 3, SLOT_FAILED = 4, SLOT_ADVANCE = 5 };
 enum { PROC_TERMINAL = 0, PROC_EVAL = 1 };
 
 struct ProcEntry {
@@ -69,20 +87,18 @@ struct EvalOut {
     float v1, v2;
 };
 
+// a level of the gather DFS while a deeper level is being processed (search.rs:561-569 GatherLevel)
 template <int NW>
-struct Level {
+struct alignas(16) Level {
     uint32_t node;
-    uint16_t next_idx, last_idx;
-    uint16_t vtp[25];
-    uint16_t pad;
-    State<NW> saved;  // position before the move that led to the next level
-};
-struct CopyFrame {
-    uint32_t old_id, new_id, slot;
+    uint32_t mask;      // child slots with allocated visits not yet processed
+    uint32_t omap[2];   // node's outcome->action maps
+    uint32_t vtp[13];   // 25 x u16 allocated visits, two per word
+    uint32_t pad[3];
+    State<NW> saved;    // position at this node
 };
 
-// search.rs:304-325 plus the sampled actions of the move
-struct MoveResult {
+struct MoveResult {  // search.rs:304-325
     float policy[2][5];
     float value[2];
     float visit_counts[2][5];
@@ -105,12 +121,12 @@ struct Slot {
     Rng rng;
     uint32_t game_index;
     uint32_t status;
-    // arena
-    NodeStats* stats;
-    NodeKids* kids;
-    uint32_t cap, lo, hi, root, node_count;
-    uint32_t pending_root;  // subtree to keep when the slot is stalled for a bigger arena
-    uint32_t need_nodes;    // capacity the stalled slot asks for
+    // arena: byte offsets from the arena base the kernels receive as an argument (so the compiler
+    // can prove the accesses are to global memory)
+    long long stats_off, kids_off, fwd_off;
+    uint32_t cap, hi, root, node_count;
+    uint32_t pending_root;  // SLOT_ADVANCE: child to keep (NIL = fresh root)
+    uint32_t need_nodes;    // capacity a stalled slot asks for
     // current search
     uint32_t remaining;
     uint32_t s_nn, s_term, s_coll;
@@ -121,18 +137,25 @@ struct Slot {
     uint32_t single_search;  // 1: ar_search mode -- stop after one search, do not move
     uint64_t t_sims, t_nn, t_term, t_coll;
     uint64_t nv_gather, nv_backup, new_nodes;
-    // per-slot scratch
-    ProcEntry* proc;      // [batch_size]
-    CollEntry* coll;      // [coll_cap]
-    Level<NW>* levels;    // [max_depth]
-    CopyFrame* frames;    // [max_depth]
-    EvalOut* ev_local;    // [batch_size] evaluator outputs when the evaluator runs inline
-    State<NW>* leaf_local;// [batch_size] leaf positions (host-callback evaluator)
-    PosRec<NW>* pos;      // [max_turns]
-    uint32_t coll_cap, max_depth;
-    MoveResult last;      // result of the last finished search
-    uint32_t error;       // non-zero: internal capacity violation (bug guard)
+    MoveResult last;  // result of the last finished search
+    uint32_t error;   // non-zero: internal capacity violation (bug guard)
     uint32_t pad0;
+};
+
+// resolved addresses of one game's memory (built per kernel from kernel arguments + slot offsets)
+template <int NW>
+struct Mem {
+    NodeStats* stats;
+    NodeKids* kids;
+    uint32_t* fwd;          // [cap] new ids during the compaction
+    ProcEntry* proc;        // [batch_size]
+    CollEntry* coll;        // [coll_cap]
+    Level<NW>* levels;      // [max_depth]
+    EvalOut* ev_local;      // [batch_size] evaluator outputs when the evaluator runs inline
+    State<NW>* leaf_local;  // [batch_size] leaf positions for evaluators outside the walk
+    PosRec<NW>* pos;        // [max_turns]
+    const uint8_t* cost;    // this game's maze
+    uint32_t coll_cap, max_depth;
 };
 
 // A leaf waiting for the device-wide evaluator (replaces MuxBackend's request queue, mux.rs:170-289)
@@ -144,31 +167,24 @@ struct LeafReq {
 };
 
 // ---- node.rs:251-283 compute_outcomes, packed ------------------------------------------------
-AR_HD void pack_outcomes(uint32_t eff, uint32_t& omap, uint8_t& n_out) {
+AR_HD void pack_outcomes(uint32_t eff, uint32_t& omap, uint32_t& n_out) {
     uint32_t present = 0;
     for (int a = 0; a < 5; ++a) present |= 1u << ((eff >> (3 * a)) & 7u);
-    uint32_t m = 0;
-    uint32_t rank[5];
-    uint32_t cnt = 0;
+    uint32_t m = 0, cnt = 0, rank_packed = 0;
     for (uint32_t act = 0; act < 5; ++act) {
-        rank[act] = cnt;
+        rank_packed |= cnt << (3 * act);
         if (present & (1u << act)) {
             m |= act << (3 * cnt);
             ++cnt;
         }
     }
-    for (int a = 0; a < 5; ++a) m |= rank[(eff >> (3 * a)) & 7u] << (15 + 3 * a);
+    for (int a = 0; a < 5; ++a) m |= ((rank_packed >> (3 * ((eff >> (3 * a)) & 7u))) & 7u) << (15 + 3 * a);
     omap = m;
-    n_out = (uint8_t)cnt;
+    n_out = cnt;
 }
 AR_HD uint32_t outcome_action(uint32_t omap, uint32_t idx) { return (omap >> (3 * idx)) & 7u; }
 AR_HD uint32_t action_outcome(uint32_t omap, uint32_t act) { return (omap >> (15 + 3 * act)) & 7u; }
 
-// node.rs:173-179 set_prior: clear, scatter-add in action order
-AR_HD void set_prior(NodeStats& nd, int pl, const float* p5) {
-    for (int i = 0; i < 5; ++i) nd.e[pl][i].prior = 0.0f;
-    for (uint32_t a = 0; a < 5; ++a) nd.e[pl][action_outcome(nd.omap[pl], a)].prior += p5[a];
-}
 // tree.rs:69-84 smart_uniform_prior from a packed effective-action map
 AR_HD void uniform_prior(uint32_t eff, float* p5) {
     uint32_t present = 0;
@@ -179,165 +195,73 @@ AR_HD void uniform_prior(uint32_t eff, float* p5) {
     for (int a = 0; a < 5; ++a) p5[a] = (present >> a) & 1u ? p : 0.0f;
 }
 
+// node.rs:173-179 set_prior: scatter-add the 5 action priors into outcome slots in action order
+AR_HD void reduce_prior(uint32_t omap, const float* p5, float* out5) {
+    for (int i = 0; i < 5; ++i) out5[i] = 0.0f;
+    for (uint32_t a = 0; a < 5; ++a) {
+        const uint32_t o = action_outcome(omap, a);
+        for (uint32_t i = 0; i < 5; ++i)
+            if (i == o) out5[i] += p5[a];
+    }
+}
+
+// shell node (tree.rs:107-148 extend_node + :199 edge rewards): all stores, no loads
 AR_HD void init_shell(NodeStats& nd, NodeKids& kd, uint32_t eff1, uint32_t eff2, uint16_t remaining,
                       uint32_t parent, uint32_t o1, uint32_t o2, float r1, float r2) {
+    Edge z;
+    z.prior = 0.0f;
+    z.q = 0.0f;
+    z.visits = 0;
+    z.nif = 0;
     for (int pl = 0; pl < 2; ++pl)
-        for (int i = 0; i < 5; ++i) {
-            nd.e[pl][i].prior = 0.0f;
-            nd.e[pl][i].q = 0.0f;
-            nd.e[pl][i].visits = 0;
-            nd.e[pl][i].nif = 0;
-        }
-    nd.v1 = 0.0f;
-    nd.v2 = 0.0f;
-    nd.visits = 0;
-    nd.nif = 0;
-    nd.scale = (float)(remaining > 1 ? remaining : 1);
-    nd.r1 = r1;
-    nd.r2 = r2;
-    nd.parent = parent;
-    pack_outcomes(eff1, nd.omap[0], nd.n[0]);
-    pack_outcomes(eff2, nd.omap[1], nd.n[1]);
-    nd.po[0] = (uint8_t)o1;
-    nd.po[1] = (uint8_t)o2;
-    nd.terminal = 0;
+        for (int i = 0; i < 5; ++i) nd.e[pl][i] = z;
+    NodeH0 h0;
+    h0.v1 = 0.0f;
+    h0.v2 = 0.0f;
+    h0.visits = 0;
+    h0.nif = 0;
+    nd.h0 = h0;
+    NodeH1 h1;
+    h1.scale = (float)(remaining > 1 ? remaining : 1);
+    h1.r1 = r1;
+    h1.r2 = r2;
+    h1.parent = parent;
+    nd.h1 = h1;
+    NodeH2 h2;
+    uint32_t n1, n2;
+    pack_outcomes(eff1, h2.omap[0], n1);
+    pack_outcomes(eff2, h2.omap[1], n2);
+    h2.meta = n1 | (n2 << 8) | (o1 << 16) | (o2 << 24);
+    h2.terminal = 0;
+    nd.h2 = h2;
     for (int i = 0; i < 25; ++i) kd.c[i] = NIL;
 }
 
-// tree.rs:351-365 alloc_root at arena index `at`
+// tree.rs:351-365 alloc_root at arena index 0 (also MCTSTree::reinit, tree.rs:298-302)
 template <int NW>
-AR_HD void make_root(Slot<NW>& s, const uint8_t* cost, uint32_t at) {
-    const uint32_t e1 = eff_actions(cost, s.st.p1, s.st.m1), e2 = eff_actions(cost, s.st.p2, s.st.m2);
-    NodeStats& nd = s.stats[at];
-    init_shell(nd, s.kids[at], e1, e2, s.st.remaining, NIL, 0, 0, 0.0f, 0.0f);
-    float p[5];
-    uniform_prior(e1, p);
-    set_prior(nd, 0, p);
-    uniform_prior(e2, p);
-    set_prior(nd, 1, p);
-    s.root = at;
-    s.lo = at;
-    s.hi = at + 1;
+AR_HD void make_root(Slot<NW>& s, const Mem<NW>& m) {
+    const uint32_t e1 = eff_actions(m.cost, s.st.p1, s.st.m1), e2 = eff_actions(m.cost, s.st.p2, s.st.m2);
+    NodeStats& nd = m.stats[0];
+    init_shell(nd, m.kids[0], e1, e2, s.st.remaining, NIL, 0, 0, 0.0f, 0.0f);
+    uint32_t om[2], nn[2];
+    pack_outcomes(e1, om[0], nn[0]);
+    pack_outcomes(e2, om[1], nn[1]);
+    float p5[5], red[5];
+    for (int pl = 0; pl < 2; ++pl) {
+        uniform_prior(pl == 0 ? e1 : e2, p5);
+        reduce_prior(om[pl], p5, red);
+        for (int i = 0; i < 5; ++i) {
+            Edge e;
+            e.prior = red[i];
+            e.q = 0.0f;
+            e.visits = 0;
+            e.nif = 0;
+            nd.e[pl][i] = e;
+        }
+    }
+    s.root = 0;
+    s.hi = 1;
     s.node_count = 1;
-}
-
-// ---- search.rs:120-152 ----------------------------------------------------------------------
-AR_HD float fpu_of(const Edge* e, int n, float node_value, float scale, float fpu_reduction) {
-    float mass = 0.0f;
-    for (int i = 0; i < n; ++i)
-        if (e[i].visits > 0) mass += e[i].prior;
-    return node_value - fpu_reduction * scale * sqrtf(mass);
-}
-
-// search.rs:463-554 estimated_visits_to_change_best_half
-AR_HD void visits_to_change_best(const Edge* e, int n, float node_value, float scale, uint32_t children_visits,
-                                 const SearchCfg& cfg, bool is_root, const uint32_t* nstarted, Rng& rng,
-                                 uint32_t& best_out, uint32_t& vtc_out) {
-    if (n <= 1) {
-        best_out = 0;
-        vtc_out = 0xFFFFFFFFu;
-        return;
-    }
-    const float fpu = fpu_of(e, n, node_value, scale, cfg.fpu_reduction);
-    const float sqrt_total = sqrtf((float)(children_visits > 1 ? children_visits : 1));
-    const float NEG_INF = -__builtin_inff();
-    float score[5], util[5];
-    for (int i = 0; i < n; ++i) {
-        const float q = e[i].visits > 0 ? e[i].q : fpu;
-        const float qn = q / scale;
-        float sc = qn + cfg.c_puct * e[i].prior * sqrt_total / (1.0f + (float)nstarted[i]);
-        if (is_root && cfg.force_k > 0.0f && e[i].prior > 0.0f) {
-            const float threshold = sqrtf(cfg.force_k * e[i].prior * (float)children_visits);
-            if ((float)e[i].visits < threshold) sc = 1e20f;
-        }
-        score[i] = sc;
-        util[i] = qn;
-    }
-    uint32_t best = 0;
-    float best_score = NEG_INF, best_util = NEG_INF, second = NEG_INF;
-    for (int i = 0; i < n; ++i) {
-        if (score[i] > best_score) {
-            second = best_score;
-            best_score = score[i];
-            best = (uint32_t)i;
-            best_util = util[i];
-        } else if (score[i] > second) {
-            second = score[i];
-        }
-    }
-    uint32_t ties = 1;
-    for (int i = 0; i < n; ++i) {
-        if ((uint32_t)i == best) continue;
-        if (fabsf(score[i] - best_score) < 1e-12f) {
-            ties += 1;
-            if (rng_below(rng, ties) == 0) {
-                best = (uint32_t)i;
-                best_util = util[i];
-            }
-        }
-    }
-    best_out = best;
-    vtc_out = 0xFFFFFFFFu;
-    if (second <= NEG_INF) return;
-    if (best_util >= second) return;
-    const float denom = second - best_util;
-    if (denom <= 0.0f) return;
-    const float n1 = (float)nstarted[best] + 1.0f;
-    float vtc = cfg.c_puct * e[best].prior * sqrt_total / denom - n1 + 1.0f;
-    if (!(vtc > 1.0f)) vtc = 1.0f;
-    const uint32_t k = vtc >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)vtc;
-    vtc_out = k > 1 ? k : 1;
-}
-
-// search.rs:742-817 build_gather_level
-template <int NW>
-AR_HD void build_level(NodeStats& nd, uint32_t node, uint32_t cur_limit, const SearchCfg& cfg, bool is_root,
-                       Rng& rng, Level<NW>& lv) {
-    const int n1 = nd.n[0], n2 = nd.n[1];
-    const uint32_t cv = nd.visits > 0 ? nd.visits - 1 : 0;
-    const float scale = nd.scale, v1 = nd.v1, v2 = nd.v2;
-    Edge e1[5], e2[5];
-    uint32_t ns1[5], ns2[5], add1[5], add2[5];
-    for (int i = 0; i < 5; ++i) {
-        e1[i] = nd.e[0][i];
-        e2[i] = nd.e[1][i];
-        ns1[i] = i < n1 ? e1[i].visits + e1[i].nif : 0;
-        ns2[i] = i < n2 ? e2[i].visits + e2[i].nif : 0;
-        add1[i] = 0;
-        add2[i] = 0;
-    }
-    lv.node = node;
-    for (int i = 0; i < 25; ++i) lv.vtp[i] = 0;
-    uint32_t remaining = cur_limit, last = 0;
-    while (remaining > 0) {
-        uint32_t b1, b2, c1, c2;
-        visits_to_change_best(e1, n1, v1, scale, cv, cfg, is_root, ns1, rng, b1, c1);
-        visits_to_change_best(e2, n2, v2, scale, cv, cfg, is_root, ns2, rng, b2, c2);
-        uint32_t k = remaining;
-        if (c1 < k) k = c1;
-        if (c2 < k) k = c2;
-        if (k < 1) k = 1;
-        const uint32_t flat = b1 * 5 + b2;
-        lv.vtp[flat] = (uint16_t)(lv.vtp[flat] + k);
-        ns1[b1] += k;
-        ns2[b2] += k;
-        add1[b1] += k;
-        add2[b2] += k;
-        remaining -= k;
-        if (flat > last) last = flat;
-    }
-    for (int i = 0; i < n1; ++i)
-        if (add1[i]) nd.e[0][i].nif += add1[i];
-    for (int j = 0; j < n2; ++j)
-        if (add2[j]) nd.e[1][j].nif += add2[j];
-    lv.next_idx = 0;
-    lv.last_idx = (uint16_t)last;
-}
-
-AR_HD bool try_start(NodeStats& nd) {  // node.rs:388-394
-    if (nd.visits == 0 && nd.nif > 0) return false;
-    nd.nif += 1;
-    return true;
 }
 
 // search.rs:437-450
@@ -355,273 +279,191 @@ AR_HD uint32_t collisions_left(uint32_t node_count, const SearchCfg& c) {
 
 // How a gathered leaf is handed to the evaluator.
 //  EVAL_UNIFORM: SmartUniform computed on the spot into ev_local (backend.rs:92-103)
-//  EVAL_STORE:   position kept in leaf_local; the step kernel then appends the batch's leaves to
-//                the device-wide leaf queue (network evaluators) or the host reads them back
-//                (predict_fn callback)
+//  EVAL_STORE:   position kept in leaf_local; the step kernel then appends the batch's leaves to the
+//                device-wide leaf queue (network evaluators) or the host reads them back (predict_fn)
 enum { EVAL_UNIFORM = 0, EVAL_STORE = 1 };
 
-struct GatherCtx {
-    const uint8_t* cost;
-    int eval_mode;
+// ---- per-player allocation state of the node being expanded (registers) ----------------------
+// Only the started count of the chosen outcome changes between two allocation steps
+// (search.rs:775-798), so q_norm, the exploration numerator c_puct*prior*sqrt_total and the forced
+// flag are computed once per node; each step recomputes one score (same expression, same bits).
+struct HalfAlloc {
+    float score[5], util[5], num[5];
+    uint32_t ns[5], add[5], nif0[5];
+    uint32_t forced;  // bit i: forced-playout score (search.rs:493-498)
+    uint32_t n;
+};
+
+AR_HD float pick5(const float* a, uint32_t i) {
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : a[4];
+}
+AR_HD uint32_t pick5u(const uint32_t* a, uint32_t i) {
+    return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : a[4];
+}
+
+// node entry: search.rs:478-498 (fpu, sqrt_total, per-outcome score) from the loaded edges
+AR_HD void half_init(HalfAlloc& h, const Edge* e, uint32_t n, float node_value, float scale, uint32_t cv,
+                     const SearchCfg& cfg, bool is_root) {
+    h.n = n;
+    h.forced = 0;
+    float mass = 0.0f;
+    for (uint32_t i = 0; i < 5; ++i)
+        if (i < n && e[i].visits > 0) mass += e[i].prior;
+    const float fpu = node_value - cfg.fpu_reduction * scale * sqrtf(mass);
+    const float sqrt_total = sqrtf((float)(cv > 1 ? cv : 1));
+    for (uint32_t i = 0; i < 5; ++i) {
+        const bool live = i < n;
+        const float q = e[i].visits > 0 ? e[i].q : fpu;
+        h.util[i] = q / scale;
+        h.num[i] = cfg.c_puct * e[i].prior * sqrt_total;
+        h.ns[i] = live ? e[i].visits + e[i].nif : 0;
+        h.nif0[i] = e[i].nif;
+        h.add[i] = 0;
+        float sc = h.util[i] + h.num[i] / (1.0f + (float)h.ns[i]);
+        if (live && is_root && cfg.force_k > 0.0f && e[i].prior > 0.0f) {
+            const float threshold = sqrtf(cfg.force_k * e[i].prior * (float)cv);
+            if ((float)e[i].visits < threshold) {
+                sc = 1e20f;
+                h.forced |= 1u << i;
+            }
+        }
+        h.score[i] = sc;
+    }
+}
+
+// search.rs:463-554 estimated_visits_to_change_best_half on the cached scores
+AR_HD void half_best(const HalfAlloc& h, Rng& rng, uint32_t& best_out, uint32_t& vtc_out) {
+    const uint32_t n = h.n;
+    if (n <= 1) {
+        best_out = 0;
+        vtc_out = 0xFFFFFFFFu;
+        return;
+    }
+    const float NEG_INF = -__builtin_inff();
+    uint32_t best = 0;
+    float best_score = NEG_INF, best_util = NEG_INF, second = NEG_INF;
+    for (uint32_t i = 0; i < 5; ++i) {
+        if (i >= n) break;
+        const float sc = h.score[i];
+        if (sc > best_score) {
+            second = best_score;
+            best_score = sc;
+            best = i;
+            best_util = h.util[i];
+        } else if (sc > second) {
+            second = sc;
+        }
+    }
+    uint32_t ties = 1;
+    for (uint32_t i = 0; i < 5; ++i) {
+        if (i >= n) break;
+        if (i == best) continue;
+        if (fabsf(h.score[i] - best_score) < 1e-12f) {
+            ties += 1;
+            if (rng_below(rng, ties) == 0) {
+                best = i;
+                best_util = h.util[i];
+            }
+        }
+    }
+    best_out = best;
+    vtc_out = 0xFFFFFFFFu;
+    if (second <= NEG_INF) return;
+    if (best_util >= second) return;
+    const float denom = second - best_util;
+    if (denom <= 0.0f) return;
+    const float n1 = (float)pick5u(h.ns, best) + 1.0f;
+    float vtc = pick5(h.num, best) / denom - n1 + 1.0f;
+    if (!(vtc > 1.0f)) vtc = 1.0f;
+    const uint32_t k = vtc >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)vtc;
+    vtc_out = k > 1 ? k : 1;
+}
+
+AR_HD void half_take(HalfAlloc& h, uint32_t b, uint32_t k) {
+    for (uint32_t i = 0; i < 5; ++i)
+        if (i == b) {
+            h.ns[i] += k;
+            h.add[i] += k;
+            if (!((h.forced >> i) & 1u)) h.score[i] = h.util[i] + h.num[i] / (1.0f + (float)h.ns[i]);
+        }
+}
+
+AR_HD uint32_t vtp_get(const uint32_t* w, uint32_t idx) {
+    uint32_t word = 0;
+    for (uint32_t j = 0; j < 13; ++j)
+        if (j == (idx >> 1)) word = w[j];
+    return (word >> (16 * (idx & 1u))) & 0xffffu;
+}
+AR_HD void vtp_add(uint32_t* w, uint32_t idx, uint32_t k) {
+    for (uint32_t j = 0; j < 13; ++j)
+        if (j == (idx >> 1)) w[j] += k << (16 * (idx & 1u));
+}
+
+AR_HD int lowest_bit(uint32_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)m) - 1;
+#else
+    return __builtin_ctz(m);
+#endif
+}
+
+// ---- gather: search.rs:961-999 (outer loop) + 576-738 (pick_nodes_to_extend) + 742-817 ---------
+enum {
+    G_PICK = 0,   // start one pick_nodes_to_extend call (or finish the gather)
+    G_ALLOC = 1,  // one allocation step at the current node
+    G_CHILD = 2,  // process the next child slot that received visits (or pop)
+    G_DONE = 3
 };
 
 template <int NW>
-AR_HD void push_proc(Slot<NW>& s, const GatherCtx& cx, const SearchCfg& cfg, uint32_t node, uint32_t kind,
+AR_HD void emit_proc(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode, uint32_t node, uint32_t kind,
                      const State<NW>& leaf) {
     if (s.n_proc >= cfg.batch_size) {
         s.error = 1;
         return;
     }
     const uint32_t i = s.n_proc++;
-    s.proc[i].node = node;
-    s.proc[i].kind = kind;
+    ProcEntry pe;
+    pe.node = node;
+    pe.kind = kind;
+    m.proc[i] = pe;
     if (kind == PROC_EVAL) {
         const uint32_t j = s.b_nn++;
-        if (cx.eval_mode == EVAL_UNIFORM) {
-            EvalOut& o = s.ev_local[j];
-            uniform_prior(eff_actions(cx.cost, leaf.p1, leaf.m1), o.p1);
-            uniform_prior(eff_actions(cx.cost, leaf.p2, leaf.m2), o.p2);
+        if (eval_mode == EVAL_UNIFORM) {
+            EvalOut o;
+            uniform_prior(eff_actions(m.cost, leaf.p1, leaf.m1), o.p1);
+            uniform_prior(eff_actions(m.cost, leaf.p2, leaf.m2), o.p2);
             o.v1 = 0.0f;
             o.v2 = 0.0f;
+            m.ev_local[j] = o;
         } else {
-            s.leaf_local[j] = leaf;
+            m.leaf_local[j] = leaf;
         }
     } else {
         s.b_term += 1;
     }
 }
 template <int NW>
-AR_HD void push_coll(Slot<NW>& s, uint32_t node, uint32_t mv) {
-    if (s.n_coll >= s.coll_cap) {
+AR_HD void emit_coll(Slot<NW>& s, const Mem<NW>& m, uint32_t node, uint32_t mv, uint32_t& pick_mv) {
+    pick_mv += mv;
+    if (s.n_coll >= m.coll_cap) {
         s.error = 2;
         return;
     }
-    s.coll[s.n_coll].node = node;
-    s.coll[s.n_coll].mv = mv;
+    CollEntry c;
+    c.node = node;
+    c.mv = mv;
+    m.coll[s.n_coll] = c;
     s.n_coll += 1;
 }
 
-// search.rs:576-738 pick_nodes_to_extend; returns the collision multivisits it produced
+// Returns false when the arena cannot take a full batch (the slot stalls untouched).
 template <int NW>
-AR_HD uint32_t pick_nodes(Slot<NW>& s, const GatherCtx& cx, const SearchCfg& cfg, uint32_t budget) {
-    const uint32_t root = s.root;
-    NodeStats& R = s.stats[root];
-    uint32_t coll_mv = 0;
-    State<NW> work = s.st;
-    if (R.visits == 0 || R.terminal) {
-        if (R.visits == 0 && !R.terminal) {
-            if (try_start(R)) {
-                if (st_over(s.board, work)) {
-                    R.terminal = 1;
-                    push_proc(s, cx, cfg, root, PROC_TERMINAL, work);
-                } else {
-                    push_proc(s, cx, cfg, root, PROC_EVAL, work);
-                }
-                if (budget > 1) {
-                    push_coll(s, root, budget - 1);
-                    coll_mv += budget - 1;
-                }
-            } else {
-                push_coll(s, root, budget);
-                coll_mv += budget;
-            }
-        } else {
-            if (R.visits == 0) R.terminal = 1;
-            if (try_start(R)) {
-                push_proc(s, cx, cfg, root, PROC_TERMINAL, work);
-                if (budget > 1) {
-                    push_coll(s, root, budget - 1);
-                    coll_mv += budget - 1;
-                }
-            } else {
-                push_coll(s, root, budget);
-                coll_mv += budget;
-            }
-        }
-        return coll_mv;
-    }
-
-    R.nif += budget;
-    build_level(R, root, budget, cfg, true, s.rng, s.levels[0]);
-    s.nv_gather += 1;
-    uint32_t depth = 1;
-    while (depth > 0) {
-        Level<NW>& L = s.levels[depth - 1];
-        bool descended = false;
-        while (L.next_idx <= L.last_idx) {
-            const uint32_t idx = L.next_idx;
-            L.next_idx += 1;
-            const uint32_t k = L.vtp[idx];
-            if (k == 0) continue;
-            const uint32_t o1 = idx / 5, o2 = idx % 5;
-            const uint32_t node = L.node;
-            NodeStats& N = s.stats[node];
-            const uint32_t act1 = outcome_action(N.omap[0], o1), act2 = outcome_action(N.omap[1], o2);
-            const State<NW> before = work;
-            float r1, r2;
-            st_step(s.board, cx.cost, work, act1, act2, r1, r2);
-            uint32_t child = s.kids[node].c[idx];
-            if (child == NIL) {
-                if (s.hi >= s.cap) {  // guarded by the pre-batch capacity check
-                    s.error = 3;
-                    work = before;
-                    continue;
-                }
-                child = s.hi++;
-                init_shell(s.stats[child], s.kids[child], eff_actions(cx.cost, work.p1, work.m1),
-                           eff_actions(cx.cost, work.p2, work.m2), work.remaining, node, o1, o2, r1, r2);
-                s.kids[node].c[idx] = child;
-                s.node_count += 1;
-                s.new_nodes += 1;
-            }
-            NodeStats& C = s.stats[child];
-            if (C.visits == 0 || C.terminal) {
-                if (try_start(C)) {
-                    if (C.terminal || st_over(s.board, work)) {
-                        if (C.visits == 0) C.terminal = 1;
-                        push_proc(s, cx, cfg, child, PROC_TERMINAL, work);
-                    } else {
-                        push_proc(s, cx, cfg, child, PROC_EVAL, work);
-                    }
-                    if (k > 1) {
-                        push_coll(s, child, k - 1);
-                        coll_mv += k - 1;
-                    }
-                } else {
-                    push_coll(s, child, k);
-                    coll_mv += k;
-                }
-                work = before;
-            } else {
-                C.nif += k;  // try_start_score_update (always succeeds on a visited node) + k-1
-                L.saved = before;
-                if (depth >= s.max_depth) {
-                    s.error = 4;
-                    work = before;
-                    continue;
-                }
-                build_level(C, child, k, cfg, false, s.rng, s.levels[depth]);
-                s.nv_gather += 1;
-                depth += 1;
-                descended = true;
-                break;
-            }
-        }
-        if (!descended) {
-            depth -= 1;
-            if (depth > 0) work = s.levels[depth - 1].saved;
-        }
-    }
-    return coll_mv;
-}
-
-// node.rs:444-457 + node.rs:82-85
-AR_HD void finalize_node(NodeStats& nd, float q1, float q2, uint32_t mv) {
-    nd.visits += mv;
-    const float n = (float)nd.visits, w = (float)mv;
-    nd.v1 += (q1 - nd.v1) * w / n;
-    nd.v2 += (q2 - nd.v2) * w / n;
-    nd.nif -= mv;
-}
-AR_HD void edge_update(Edge& e, float value, uint32_t mv) {
-    e.visits += mv;
-    e.q += (value - e.q) * (float)mv / (float)e.visits;
-    e.nif -= mv;
-}
-
-// search.rs:826-852 backup_and_finalize
-template <int NW>
-AR_HD void backup_path(Slot<NW>& s, uint32_t leaf, float g1, float g2, uint32_t mv) {
-    finalize_node(s.stats[leaf], g1, g2, mv);
-    s.nv_backup += 1;
-    float v1 = g1, v2 = g2;
-    uint32_t cur = leaf;
-    for (;;) {
-        const NodeStats& C = s.stats[cur];
-        const uint32_t parent = C.parent;
-        if (parent == NIL) break;
-        const float q1 = C.r1 + v1, q2 = C.r2 + v2;
-        const uint32_t a1 = C.po[0], a2 = C.po[1];
-        NodeStats& P = s.stats[parent];
-        finalize_node(P, q1, q2, mv);
-        edge_update(P.e[0][a1], q1, mv);
-        edge_update(P.e[1][a2], q2, mv);
-        s.nv_backup += 1;
-        v1 = q1;
-        v2 = q2;
-        cur = parent;
-    }
-}
-
-// search.rs:860-889 cancel_shared_collisions (the root has no parent, so the walk ends there)
-template <int NW>
-AR_HD void cancel_collisions(Slot<NW>& s) {
-    for (uint32_t i = 0; i < s.n_coll; ++i) {
-        const uint32_t mv = s.coll[i].mv;
-        uint32_t cur = s.coll[i].node;
-        for (;;) {
-            const NodeStats& C = s.stats[cur];
-            const uint32_t parent = C.parent;
-            if (parent == NIL) break;
-            NodeStats& P = s.stats[parent];
-            P.nif -= mv;
-            P.e[0][C.po[0]].nif -= mv;
-            P.e[1][C.po[1]].nif -= mv;
-            cur = parent;
-        }
-    }
-}
-// search.rs:899-910 + :945-955: revert a gathered batch after an evaluator failure
-template <int NW>
-AR_HD void cancel_batch(Slot<NW>& s) {
-    for (uint32_t i = 0; i < s.n_proc; ++i) {
-        uint32_t cur = s.proc[i].node;
-        s.stats[cur].nif -= 1;
-        for (;;) {
-            const NodeStats& C = s.stats[cur];
-            const uint32_t parent = C.parent;
-            if (parent == NIL) break;
-            NodeStats& P = s.stats[parent];
-            P.nif -= 1;
-            P.e[0][C.po[0]].nif -= 1;
-            P.e[1][C.po[1]].nif -= 1;
-            cur = parent;
-        }
-    }
-    cancel_collisions(s);
-    s.n_proc = 0;
-    s.n_coll = 0;
-    s.batch_active = 0;
-}
-
-// search.rs:400-429 apply_dirichlet_noise (shape = concentration / n >= 1 path of rand_distr Gamma)
-AR_HD bool dirichlet_noise(NodeStats& nd, int pl, float epsilon, float concentration, Rng& rng, const ZigTables* zt) {
-    const int n = nd.n[pl];
-    if (n <= 1) return true;
-    const double alpha = (double)(concentration / (float)n);
-    if (!(alpha > 0.0)) return true;
-    if (alpha <= 1.0) return false;
-    float noise[5];
-    float total = 0.0f;
-    for (int i = 0; i < n; ++i) {
-        noise[i] = (float)rng_gamma(rng, alpha, zt);
-        total += noise[i];
-    }
-    if (total < 1.17549435e-38f) return true;
-    for (int i = 0; i < n; ++i)
-        nd.e[pl][i].prior = nd.e[pl][i].prior * (1.0f - epsilon) + epsilon * noise[i] / total;
-    return true;
-}
-
-// ---- one simulate_batch, split at the evaluator boundary (search.rs:961-1073) ----------------
-// gather: returns false when the arena cannot take a full batch (slot stalls untouched)
-template <int NW>
-AR_HD bool gather_batch(Slot<NW>& s, const GatherCtx& cx, const SearchCfg& cfg) {
+AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode) {
     const uint32_t batch = s.remaining < cfg.batch_size ? s.remaining : cfg.batch_size;
     if (s.hi + batch > s.cap) {
         s.status = SLOT_STALL;
-        s.pending_root = s.root;
-        s.need_nodes = s.node_count + cfg.n_sims + 2 * cfg.batch_size;
+        s.need_nodes = s.hi + cfg.n_sims + 2 * cfg.batch_size;
         return false;
     }
     long long left = (long long)(int32_t)collisions_left(s.node_count, cfg);
@@ -630,39 +472,342 @@ AR_HD bool gather_batch(Slot<NW>& s, const GatherCtx& cx, const SearchCfg& cfg) 
     s.b_nn = 0;
     s.b_term = 0;
     s.b_coll = 0;
-    while (s.n_proc < batch && left > 0) {
-        uint32_t budget = (uint32_t)left;
-        if (batch - s.n_proc < budget) budget = batch - s.n_proc;
-        const uint32_t mv = pick_nodes(s, cx, cfg, budget);
-        s.b_coll += mv;
-        left -= (long long)mv;
+
+    uint32_t state = G_PICK;
+    uint32_t depth = 0;      // levels on the stack below the current one
+    uint32_t node = 0;       // current node
+    uint32_t remaining = 0;  // visits still to allocate at the current node
+    uint32_t mask = 0;       // child slots of the current node still to process
+    uint32_t omap0 = 0, omap1 = 0;
+    uint32_t vtp[13];
+    uint32_t pick_mv = 0;
+    bool have_pick = false;
+    HalfAlloc h1, h2;
+    State<NW> work = s.st;
+    for (int j = 0; j < 13; ++j) vtp[j] = 0;
+    h1.n = h2.n = 0;
+    h1.forced = h2.forced = 0;
+    for (int j = 0; j < 5; ++j) {
+        h1.score[j] = h1.util[j] = h1.num[j] = 0.0f;
+        h2.score[j] = h2.util[j] = h2.num[j] = 0.0f;
+        h1.ns[j] = h1.add[j] = h1.nif0[j] = 0;
+        h2.ns[j] = h2.add[j] = h2.nif0[j] = 0;
+    }
+
+    while (state != G_DONE) {
+        uint32_t enter = NIL, enter_budget = 0;  // node to load for expansion at the end of this step
+        bool enter_root = false;
+        if (state == G_ALLOC) {
+            // search.rs:775-798, one step
+            uint32_t b1, b2, c1, c2;
+            half_best(h1, s.rng, b1, c1);
+            half_best(h2, s.rng, b2, c2);
+            uint32_t k = remaining;
+            if (c1 < k) k = c1;
+            if (c2 < k) k = c2;
+            if (k < 1) k = 1;
+            const uint32_t flat = b1 * 5 + b2;
+            vtp_add(vtp, flat, k);
+            mask |= 1u << flat;
+            half_take(h1, b1, k);
+            half_take(h2, b2, k);
+            remaining -= k;
+            if (remaining == 0) {
+                // search.rs:800-814: write the virtual-loss deltas back
+                NodeStats& N = m.stats[node];
+                for (uint32_t i = 0; i < 5; ++i) {
+                    if (h1.add[i]) N.e[0][i].nif = h1.nif0[i] + h1.add[i];
+                    if (h2.add[i]) N.e[1][i].nif = h2.nif0[i] + h2.add[i];
+                }
+                state = G_CHILD;
+            }
+        } else if (state == G_CHILD) {
+            if (mask == 0) {
+                // level exhausted: backtrack (search.rs:728-734)
+                if (depth == 0) {
+                    state = G_PICK;
+                } else {
+                    depth -= 1;
+                    const Level<NW>& L = m.levels[depth];
+                    node = L.node;
+                    mask = L.mask;
+                    omap0 = L.omap[0];
+                    omap1 = L.omap[1];
+                    for (int j = 0; j < 13; ++j) vtp[j] = L.vtp[j];
+                    work = L.saved;
+                }
+            } else {
+                const uint32_t idx = (uint32_t)lowest_bit(mask);
+                mask &= mask - 1;
+                const uint32_t k = vtp_get(vtp, idx);
+                const uint32_t o1 = idx / 5, o2 = idx % 5;
+                const State<NW> before = work;
+                float r1, r2;
+                st_step(s.board, m.cost, work, outcome_action(omap0, o1), outcome_action(omap1, o2), r1, r2);
+                uint32_t child = m.kids[node].c[idx];
+                bool leaf_path = true, ok = true;
+                uint32_t c_visits = 0, c_nif = 0, c_term = 0;
+                if (child == NIL) {
+                    if (s.hi >= s.cap) {  // excluded by the capacity check above
+                        s.error = 3;
+                        ok = false;
+                    } else {
+                        child = s.hi++;
+                        init_shell(m.stats[child], m.kids[child], eff_actions(m.cost, work.p1, work.m1),
+                                   eff_actions(m.cost, work.p2, work.m2), work.remaining, node, o1, o2, r1, r2);
+                        m.kids[node].c[idx] = child;
+                        s.node_count += 1;
+                        s.new_nodes += 1;
+                    }
+                } else {
+                    const NodeH0 a = m.stats[child].h0;
+                    c_visits = a.visits;
+                    c_nif = a.nif;
+                    c_term = m.stats[child].h2.terminal;
+                    leaf_path = c_visits == 0 || c_term != 0;
+                }
+                if (!ok) {
+                    work = before;
+                } else if (leaf_path) {
+                    // search.rs:675-706
+                    if (!(c_visits == 0 && c_nif > 0)) {  // try_start_score_update
+                        m.stats[child].h0.nif = c_nif + 1;
+                        if (c_term != 0 || st_over(s.board, work)) {
+                            if (c_visits == 0) m.stats[child].h2.terminal = 1;
+                            emit_proc(s, m, cfg, eval_mode, child, PROC_TERMINAL, work);
+                        } else {
+                            emit_proc(s, m, cfg, eval_mode, child, PROC_EVAL, work);
+                        }
+                        if (k > 1) emit_coll(s, m, child, k - 1, pick_mv);
+                    } else {
+                        emit_coll(s, m, child, k, pick_mv);
+                    }
+                    work = before;
+                } else if (depth >= m.max_depth) {
+                    s.error = 4;
+                    work = before;
+                } else {
+                    // search.rs:707-725: interior child, descend with k visits
+                    m.stats[child].h0.nif = c_nif + k;
+                    Level<NW>& L = m.levels[depth];
+                    L.node = node;
+                    L.mask = mask;
+                    L.omap[0] = omap0;
+                    L.omap[1] = omap1;
+                    for (int j = 0; j < 13; ++j) L.vtp[j] = vtp[j];
+                    L.saved = before;
+                    depth += 1;
+                    enter = child;
+                    enter_budget = k;
+                }
+            }
+        } else {  // G_PICK
+            if (have_pick) {
+                s.b_coll += pick_mv;
+                left -= (long long)pick_mv;
+                have_pick = false;
+            }
+            if (!(s.n_proc < batch && left > 0)) {
+                state = G_DONE;
+            } else {
+                uint32_t budget = (uint32_t)left;
+                if (batch - s.n_proc < budget) budget = batch - s.n_proc;
+                pick_mv = 0;
+                have_pick = true;
+                work = s.st;
+                depth = 0;
+                const uint32_t root = s.root;
+                const NodeH0 a = m.stats[root].h0;
+                const uint32_t term = m.stats[root].h2.terminal;
+                if (a.visits == 0 || term) {
+                    // search.rs:591-636: unvisited or terminal root
+                    const bool claim = !(a.visits == 0 && a.nif > 0);
+                    if (claim) {
+                        m.stats[root].h0.nif = a.nif + 1;
+                        if (term || st_over(s.board, work)) {
+                            if (a.visits == 0) m.stats[root].h2.terminal = 1;
+                            emit_proc(s, m, cfg, eval_mode, root, PROC_TERMINAL, work);
+                        } else {
+                            emit_proc(s, m, cfg, eval_mode, root, PROC_EVAL, work);
+                        }
+                        if (budget > 1) emit_coll(s, m, root, budget - 1, pick_mv);
+                    } else {
+                        emit_coll(s, m, root, budget, pick_mv);
+                    }
+                    // stay in G_PICK: the next iteration accounts for this pick
+                } else {
+                    m.stats[root].h0.nif = a.nif + budget;  // search.rs:639
+                    enter = root;
+                    enter_budget = budget;
+                    enter_root = true;
+                }
+            }
+        }
+        if (enter != NIL) {
+            // load the node for expansion: everything select needs arrives in one round trip
+            const NodeStats& N = m.stats[enter];
+            Edge e1[5], e2[5];
+            for (int i = 0; i < 5; ++i) {
+                e1[i] = N.e[0][i];
+                e2[i] = N.e[1][i];
+            }
+            const NodeH0 a = N.h0;
+            const NodeH1 b = N.h1;
+            const NodeH2 c = N.h2;
+            const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
+            half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, enter_root);
+            half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, enter_root);
+            node = enter;
+            remaining = enter_budget;
+            omap0 = c.omap[0];
+            omap1 = c.omap[1];
+            mask = 0;
+            for (int j = 0; j < 13; ++j) vtp[j] = 0;
+            s.nv_gather += 1;
+            state = G_ALLOC;
+        }
     }
     s.batch_active = 1;
     return true;
 }
 
-// backup: `ev` holds b_nn results in gather order. Returns true when the search is complete.
-template <int NW>
-AR_HD bool backup_batch(Slot<NW>& s, const SearchCfg& cfg, const EvalOut* ev, const ZigTables* zt) {
-    uint32_t j = 0;
-    for (uint32_t i = 0; i < s.n_proc; ++i) {
-        const uint32_t node = s.proc[i].node;
-        if (s.proc[i].kind == PROC_EVAL) {
-            const EvalOut& o = ev[j++];
-            NodeStats& nd = s.stats[node];
-            set_prior(nd, 0, o.p1);
-            set_prior(nd, 1, o.p2);
-            if (node == s.root && cfg.noise_epsilon > 0.0f) {
-                const bool ok1 = dirichlet_noise(nd, 0, cfg.noise_epsilon, cfg.noise_concentration, s.rng, zt);
-                const bool ok2 = dirichlet_noise(nd, 1, cfg.noise_epsilon, cfg.noise_concentration, s.rng, zt);
-                if (!ok1 || !ok2) s.error = 5;
-            }
-            backup_path(s, node, o.v1, o.v2, 1);
-        } else {
-            backup_path(s, node, 0.0f, 0.0f, 1);
+// ---- backup: search.rs:1027-1066 ---------------------------------------------------------------
+// node.rs:444-457 on a loaded header
+AR_HD void finalize_h0(NodeH0& a, float q1, float q2, uint32_t mv) {
+    a.visits += mv;
+    const float n = (float)a.visits, w = (float)mv;
+    a.v1 += (q1 - a.v1) * w / n;
+    a.v2 += (q2 - a.v2) * w / n;
+    a.nif -= mv;
+}
+// node.rs:82-85 + revert_virtual_loss_multi
+AR_HD void edge_update(Edge& e, float value, uint32_t mv) {
+    e.visits += mv;
+    e.q += (value - e.q) * (float)mv / (float)e.visits;
+    e.nif -= mv;
+}
+
+// search.rs:400-429 apply_dirichlet_noise on the reduced priors (shape = concentration/n > 1 only)
+AR_HD bool dirichlet_mix(float* prior, uint32_t n, float epsilon, float concentration, Rng& rng, const ZigTables* zt) {
+    if (n <= 1) return true;
+    const double alpha = (double)(concentration / (float)n);
+    if (!(alpha > 0.0)) return true;
+    if (alpha <= 1.0) return false;
+    float noise[5];
+    float total = 0.0f;
+    for (uint32_t i = 0; i < 5; ++i) {
+        noise[i] = 0.0f;
+        if (i < n) {
+            noise[i] = (float)rng_gamma(rng, alpha, zt);
+            total += noise[i];
         }
     }
-    cancel_collisions(s);
+    if (total < 1.17549435e-38f) return true;
+    for (uint32_t i = 0; i < 5; ++i)
+        if (i < n) prior[i] = prior[i] * (1.0f - epsilon) + epsilon * noise[i] / total;
+    return true;
+}
+
+enum { B_ENTRY = 0, B_LEVEL = 1, B_CANCEL = 2, B_CANCEL_LEVEL = 3, B_DONE = 4 };
+
+// `ev` holds b_nn results in gather order. Returns true when the search is complete.
+template <int NW>
+AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const EvalOut* ev, const ZigTables* zt) {
+    uint32_t state = B_ENTRY;
+    uint32_t i = 0, j = 0;  // proc index, eval index
+    uint32_t parent = 0, po = 0, mv = 0;
+    float v1 = 0.0f, v2 = 0.0f, cr1 = 0.0f, cr2 = 0.0f;
+    while (state != B_DONE) {
+        if (state == B_LEVEL) {
+            // search.rs:834-851 one ancestor: everything of the parent arrives in one round trip
+            NodeStats& P = m.stats[parent];
+            NodeH0 a = P.h0;
+            const NodeH1 b = P.h1;
+            const NodeH2 c = P.h2;
+            const uint32_t a1 = po & 0xffu, a2 = po >> 8;
+            Edge e1 = P.e[0][a1], e2 = P.e[1][a2];
+            const float q1 = cr1 + v1, q2 = cr2 + v2;
+            finalize_h0(a, q1, q2, 1);
+            edge_update(e1, q1, 1);
+            edge_update(e2, q2, 1);
+            P.h0 = a;
+            P.e[0][a1] = e1;
+            P.e[1][a2] = e2;
+            s.nv_backup += 1;
+            v1 = q1;
+            v2 = q2;
+            cr1 = b.r1;
+            cr2 = b.r2;
+            po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+            parent = b.parent;
+            if (parent == NIL) state = B_ENTRY;
+        } else if (state == B_ENTRY) {
+            if (i >= s.n_proc) {
+                i = 0;
+                state = B_CANCEL;
+            } else {
+                const ProcEntry pe = m.proc[i++];
+                NodeStats& N = m.stats[pe.node];
+                NodeH0 a = N.h0;
+                const NodeH1 b = N.h1;
+                const NodeH2 c = N.h2;
+                float g1 = 0.0f, g2 = 0.0f;
+                if (pe.kind == PROC_EVAL) {
+                    const EvalOut o = ev[j++];
+                    float red1[5], red2[5];
+                    reduce_prior(c.omap[0], o.p1, red1);  // populate_node (tree.rs:156-173)
+                    reduce_prior(c.omap[1], o.p2, red2);
+                    if (pe.node == s.root && cfg.noise_epsilon > 0.0f) {  // search.rs:1036-1050
+                        const bool ok1 = dirichlet_mix(red1, meta_n(c.meta, 0), cfg.noise_epsilon, cfg.noise_concentration,
+                                                       s.rng, zt);
+                        const bool ok2 = dirichlet_mix(red2, meta_n(c.meta, 1), cfg.noise_epsilon, cfg.noise_concentration,
+                                                       s.rng, zt);
+                        if (!ok1 || !ok2) s.error = 5;
+                    }
+                    for (int k = 0; k < 5; ++k) {
+                        N.e[0][k].prior = red1[k];
+                        N.e[1][k].prior = red2[k];
+                    }
+                    g1 = o.v1;
+                    g2 = o.v2;
+                }
+                finalize_h0(a, g1, g2, 1);  // leaf: finalize_score_update
+                N.h0 = a;
+                s.nv_backup += 1;
+                v1 = g1;
+                v2 = g2;
+                cr1 = b.r1;
+                cr2 = b.r2;
+                po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+                parent = b.parent;
+                if (parent != NIL) state = B_LEVEL;
+            }
+        } else if (state == B_CANCEL) {
+            // search.rs:860-889 cancel_shared_collisions
+            if (i >= s.n_coll) {
+                state = B_DONE;
+            } else {
+                const CollEntry ce = m.coll[i++];
+                mv = ce.mv;
+                const NodeH1 b = m.stats[ce.node].h1;
+                const NodeH2 c = m.stats[ce.node].h2;
+                po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+                parent = b.parent;
+                if (parent != NIL) state = B_CANCEL_LEVEL;
+            }
+        } else {  // B_CANCEL_LEVEL
+            NodeStats& P = m.stats[parent];
+            const NodeH1 b = P.h1;
+            const NodeH2 c = P.h2;
+            const uint32_t a1 = po & 0xffu, a2 = po >> 8;
+            P.h0.nif -= mv;
+            P.e[0][a1].nif -= mv;
+            P.e[1][a2].nif -= mv;
+            po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+            parent = b.parent;
+            if (parent == NIL) state = B_CANCEL;
+        }
+    }
     s.s_nn += s.b_nn;
     s.s_term += s.b_term;
     s.s_coll += s.b_coll;
@@ -675,44 +820,79 @@ AR_HD bool backup_batch(Slot<NW>& s, const SearchCfg& cfg, const EvalOut* ev, co
     return s.remaining == 0;
 }
 
+// search.rs:899-910 + :945-955: revert a gathered batch after an evaluator failure
+template <int NW>
+AR_HD void cancel_batch(Slot<NW>& s, const Mem<NW>& m) {
+    for (uint32_t i = 0; i < s.n_proc; ++i) {
+        uint32_t cur = m.proc[i].node;
+        m.stats[cur].h0.nif -= 1;
+        for (;;) {
+            const uint32_t parent = m.stats[cur].h1.parent;
+            if (parent == NIL) break;
+            const uint32_t meta = m.stats[cur].h2.meta;
+            NodeStats& P = m.stats[parent];
+            P.h0.nif -= 1;
+            P.e[0][meta_po(meta, 0)].nif -= 1;
+            P.e[1][meta_po(meta, 1)].nif -= 1;
+            cur = parent;
+        }
+    }
+    for (uint32_t i = 0; i < s.n_coll; ++i) {
+        const uint32_t mv = m.coll[i].mv;
+        uint32_t cur = m.coll[i].node;
+        for (;;) {
+            const uint32_t parent = m.stats[cur].h1.parent;
+            if (parent == NIL) break;
+            const uint32_t meta = m.stats[cur].h2.meta;
+            NodeStats& P = m.stats[parent];
+            P.h0.nif -= mv;
+            P.e[0][meta_po(meta, 0)].nif -= mv;
+            P.e[1][meta_po(meta, 1)].nif -= mv;
+            cur = parent;
+        }
+    }
+    s.n_proc = 0;
+    s.n_coll = 0;
+    s.batch_active = 0;
+}
+
 // ---- search.rs:249-296, 1079-1177: result extraction -----------------------------------------
-AR_HD void extract_player(const NodeStats& nd, int pl, float node_value, const SearchCfg& cfg, float* policy,
-                          float* visit_counts, float* prior5, float& value) {
-    const int n = nd.n[pl];
-    const Edge* e = nd.e[pl];
-    const uint32_t cv = nd.visits > 0 ? nd.visits - 1 : 0;
+AR_HD void extract_player(const Edge* e, uint32_t n, uint32_t omap, float node_value, float scale, uint32_t visits,
+                          const SearchCfg& cfg, float* policy, float* visit_counts, float* prior5, float& value) {
+    const uint32_t cv = visits > 0 ? visits - 1 : 0;
     for (int i = 0; i < 5; ++i) {
         policy[i] = 0.0f;
         visit_counts[i] = 0.0f;
         prior5[i] = 0.0f;
     }
-    for (int i = 0; i < n; ++i) prior5[outcome_action(nd.omap[pl], i)] = e[i].prior;
-    if (n == 0) {
-        value = node_value;
-        return;
-    }
-    const float fpu = fpu_of(e, n, node_value, nd.scale, cfg.fpu_reduction);
+    float mass = 0.0f;
+    for (uint32_t i = 0; i < 5; ++i)
+        if (i < n && e[i].visits > 0) mass += e[i].prior;
+    const float fpu = node_value - cfg.fpu_reduction * scale * sqrtf(mass);
     float q[5], raw[5], qn[5], pruned[5];
-    for (int i = 0; i < 5; ++i) {
-        q[i] = 0.0f;
-        raw[i] = 0.0f;
-        qn[i] = 0.0f;
+    for (uint32_t i = 0; i < 5; ++i) {
+        const bool live = i < n;
+        q[i] = live ? (e[i].visits > 0 ? e[i].q : fpu) : 0.0f;
+        raw[i] = live ? (float)e[i].visits : 0.0f;
+        qn[i] = live ? q[i] / scale : 0.0f;
         pruned[i] = 0.0f;
-    }
-    for (int i = 0; i < n; ++i) {
-        q[i] = e[i].visits > 0 ? e[i].q : fpu;
-        raw[i] = (float)e[i].visits;
-        qn[i] = q[i] / nd.scale;
     }
     if (n == 1) {
         pruned[0] = raw[0];
     } else {
-        int best = 0;
-        for (int i = 1; i < n; ++i)
-            if (raw[i] > raw[best]) best = i;
+        uint32_t best = 0;
+        float best_v = raw[0], best_qn = qn[0], best_prior = e[0].prior;
+        for (uint32_t i = 1; i < 5; ++i)
+            if (i < n && raw[i] > best_v) {
+                best = i;
+                best_v = raw[i];
+                best_qn = qn[i];
+                best_prior = e[i].prior;
+            }
         const float sqrt_total = sqrtf((float)(cv > 1 ? cv : 1));
-        const float puct_star = qn[best] + cfg.c_puct * e[best].prior * sqrt_total / (1.0f + raw[best]);
-        for (int i = 0; i < n; ++i) {
+        const float puct_star = best_qn + cfg.c_puct * best_prior * sqrt_total / (1.0f + best_v);
+        for (uint32_t i = 0; i < 5; ++i) {
+            if (i >= n) break;
             if (i == best || qn[i] >= puct_star) {
                 pruned[i] = raw[i];
             } else {
@@ -727,7 +907,15 @@ AR_HD void extract_player(const NodeStats& nd, int pl, float node_value, const S
             }
         }
     }
-    for (int i = 0; i < n; ++i) visit_counts[outcome_action(nd.omap[pl], i)] = pruned[i];
+    for (uint32_t i = 0; i < 5; ++i) {
+        if (i >= n) break;
+        const uint32_t act = outcome_action(omap, i);
+        for (uint32_t a = 0; a < 5; ++a)
+            if (a == act) {
+                visit_counts[a] = pruned[i];
+                prior5[a] = e[i].prior;
+            }
+    }
     float sum = 0.0f;
     for (int i = 0; i < 5; ++i) sum += visit_counts[i];
     if (sum > 0.0f) {
@@ -736,10 +924,12 @@ AR_HD void extract_player(const NodeStats& nd, int pl, float node_value, const S
         for (int i = 0; i < 5; ++i) policy[i] = prior5[i];
     }
     float vs = 0.0f;
-    for (int i = 0; i < n; ++i) vs += raw[i];
+    for (uint32_t i = 0; i < 5; ++i)
+        if (i < n) vs += raw[i];
     if (vs > 0.0f) {
         float dot = 0.0f;
-        for (int i = 0; i < n; ++i) dot += q[i] * raw[i];
+        for (uint32_t i = 0; i < 5; ++i)
+            if (i < n) dot += q[i] * raw[i];
         value = dot / vs;
     } else {
         value = node_value;
@@ -747,98 +937,35 @@ AR_HD void extract_player(const NodeStats& nd, int pl, float node_value, const S
 }
 
 template <int NW>
-AR_HD void extract_result(const Slot<NW>& s, const SearchCfg& cfg, MoveResult& r) {
-    const NodeStats& R = s.stats[s.root];
-    extract_player(R, 0, R.v1, cfg, r.policy[0], r.visit_counts[0], r.prior[0], r.value[0]);
-    extract_player(R, 1, R.v2, cfg, r.policy[1], r.visit_counts[1], r.prior[1], r.value[1]);
-    r.total_visits = R.visits;
+AR_HD void extract_result(const Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, MoveResult& r) {
+    const NodeStats& R = m.stats[s.root];
+    Edge e1[5], e2[5];
+    for (int i = 0; i < 5; ++i) {
+        e1[i] = R.e[0][i];
+        e2[i] = R.e[1][i];
+    }
+    const NodeH0 a = R.h0;
+    const NodeH1 b = R.h1;
+    const NodeH2 c = R.h2;
+    extract_player(e1, meta_n(c.meta, 0), c.omap[0], a.v1, b.scale, a.visits, cfg, r.policy[0], r.visit_counts[0],
+                   r.prior[0], r.value[0]);
+    extract_player(e2, meta_n(c.meta, 1), c.omap[1], a.v2, b.scale, a.visits, cfg, r.policy[1], r.visit_counts[1],
+                   r.prior[1], r.value[1]);
+    r.total_visits = a.visits;
     r.nn_evals = s.s_nn;
     r.terminals = s.s_term;
     r.collisions = s.s_coll;
 }
 
-// ---- tree reuse: tree.rs:283-302 --------------------------------------------------------------
-// Copy the subtree under `src_root` of (src_stats, src_kids) to dst[dst_at ...) in DFS pre-order.
-// Returns the number of nodes copied (the reference's count_subtree_nodes, tree.rs:209-226).
-AR_HD uint32_t copy_subtree(const NodeStats* src_stats, const NodeKids* src_kids, uint32_t src_root,
-                            NodeStats* dst_stats, NodeKids* dst_kids, uint32_t dst_at, CopyFrame* frames,
-                            uint32_t max_depth, uint32_t& error) {
-    uint32_t next = dst_at;
-    dst_stats[next] = src_stats[src_root];
-    dst_stats[next].parent = NIL;
-    for (int i = 0; i < 25; ++i) dst_kids[next].c[i] = NIL;
-    frames[0].old_id = src_root;
-    frames[0].new_id = next;
-    frames[0].slot = 0;
-    next += 1;
-    uint32_t depth = 1;
-    while (depth > 0) {
-        CopyFrame& f = frames[depth - 1];
-        uint32_t child = NIL, sl = f.slot;
-        while (sl < 25) {
-            child = src_kids[f.old_id].c[sl];
-            if (child != NIL) break;
-            ++sl;
-        }
-        if (sl >= 25) {
-            depth -= 1;
-            continue;
-        }
-        f.slot = sl + 1;
-        const uint32_t nn = next++;
-        dst_stats[nn] = src_stats[child];
-        dst_stats[nn].parent = f.new_id;
-        for (int i = 0; i < 25; ++i) dst_kids[nn].c[i] = NIL;
-        dst_kids[f.new_id].c[sl] = nn;
-        if (depth >= max_depth) {
-            error = 6;
-            continue;
-        }
-        frames[depth].old_id = child;
-        frames[depth].new_id = nn;
-        frames[depth].slot = 0;
-        depth += 1;
-    }
-    return next - dst_at;
-}
-
-// After the real move (a1, a2): keep the matching child's subtree or start a fresh root.
+// The end of one self-play turn (selfplay.rs:538-565) up to the tree reuse: extract, sample both
+// actions, record, move. Leaves the slot in SLOT_ADVANCE (tree to be re-rooted by advance_tree_*)
+// or SLOT_DONE (game over / single search): the tree work is done by a whole wavefront afterwards.
 template <int NW>
-AR_HD void advance_or_reinit(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg, uint32_t a1, uint32_t a2) {
-    const NodeStats& R = s.stats[s.root];
-    const uint32_t i = action_outcome(R.omap[0], a1), j = action_outcome(R.omap[1], a2);
-    const uint32_t child = s.kids[s.root].c[i * 5 + j];
-    if (child == NIL) {
-        make_root(s, cost, 0);  // reinit (tree.rs:298-302)
-        return;
-    }
-    // upper bound on the kept subtree: every node was created by one visit of that child
-    uint32_t bound = s.stats[child].visits + 1;
-    if (bound > s.node_count) bound = s.node_count;
-    uint32_t at;
-    if (s.lo >= bound) at = 0;
-    else if (s.cap - s.hi >= bound) at = s.hi;
-    else {
-        s.status = SLOT_STALL;
-        s.pending_root = child;
-        s.need_nodes = bound + cfg.n_sims + 2 * cfg.batch_size;
-        return;
-    }
-    const uint32_t cnt = copy_subtree(s.stats, s.kids, child, s.stats, s.kids, at, s.frames, s.max_depth, s.error);
-    s.root = at;
-    s.lo = at;
-    s.hi = at + cnt;
-    s.node_count = cnt;
-}
-
-// The end of one self-play turn (selfplay.rs:538-565): extract, sample both actions, record, move,
-// reuse the tree. Returns true when the game is over.
-template <int NW>
-AR_HD bool finish_move(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg) {
-    extract_result(s, cfg, s.last);
+AR_HD void finish_move(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
+    extract_result(s, m, cfg, s.last);
     if (s.single_search) {
         s.status = SLOT_DONE;
-        return true;
+        return;
     }
     s.t_sims += s.last.total_visits;
     s.t_nn += s.last.nn_evals;
@@ -849,7 +976,7 @@ AR_HD bool finish_move(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg) {
     int a2 = rng_weighted5(s.rng, s.last.policy[1]);
     if (a2 < 0) a2 = 4;
     if (s.n_pos < s.board.max_turns) {
-        PosRec<NW>& p = s.pos[s.n_pos];
+        PosRec<NW>& p = m.pos[s.n_pos];
         p.st = s.st;
         p.res = s.last;
         p.a1 = (uint8_t)a1;
@@ -858,24 +985,68 @@ AR_HD bool finish_move(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg) {
         s.error = 7;
     }
     s.n_pos += 1;
+    // tree.rs:284-285: the child to keep, looked up before the position changes
+    const NodeH2 c = m.stats[s.root].h2;
+    const uint32_t ci = action_outcome(c.omap[0], (uint32_t)a1) * 5 + action_outcome(c.omap[1], (uint32_t)a2);
+    const uint32_t child = m.kids[s.root].c[ci];
     float r1, r2;
-    st_step(s.board, cost, s.st, (uint32_t)a1, (uint32_t)a2, r1, r2);
+    st_step(s.board, m.cost, s.st, (uint32_t)a1, (uint32_t)a2, r1, r2);
     if (st_over(s.board, s.st)) {
         s.status = SLOT_DONE;
-        return true;
+        return;
     }
     s.remaining = cfg.n_sims;
     s.s_nn = 0;
     s.s_term = 0;
     s.s_coll = 0;
-    advance_or_reinit(s, cost, cfg, (uint32_t)a1, (uint32_t)a2);
-    return false;
+    s.pending_root = child;
+    s.status = SLOT_ADVANCE;
 }
 
-// Start a game in a slot (selfplay.rs:526-535). The caller has filled board, st, rng, arena and
-// scratch pointers.
+// ---- tree reuse: tree.rs:283-302 as an in-place sliding compaction ------------------------------
+// Ids grow from parent to child, so one pass in id order decides what is kept (keep[i] =
+// keep[parent[i]]), assigns new ids (prefix count of kept nodes) and -- because new id <= old id --
+// nodes can move in place. fwd[] holds the new id of every old node (NIL = dropped).
+// This scalar form is what one lane does (CPU harness, growth path); the kernel runs the same two
+// passes with a wavefront per game. Both give the same tree.
 template <int NW>
-AR_HD void start_game(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg) {
+AR_HD void advance_tree_scalar(Slot<NW>& s, const Mem<NW>& m) {
+    const uint32_t keep_root = s.pending_root;
+    if (keep_root == NIL) {
+        make_root(s, m);
+        s.status = SLOT_ACTIVE;
+        return;
+    }
+    const uint32_t hi = s.hi;
+    uint32_t cnt = 0;
+    for (uint32_t i = 0; i < hi; ++i) {
+        bool keep = i == keep_root;
+        if (!keep && i > keep_root) {
+            const uint32_t p = m.stats[i].h1.parent;
+            keep = p != NIL && m.fwd[p] != NIL;
+        }
+        m.fwd[i] = keep ? cnt++ : NIL;
+    }
+    for (uint32_t i = keep_root; i < hi; ++i) {
+        const uint32_t ni = m.fwd[i];
+        if (ni == NIL) continue;
+        NodeStats nd = m.stats[i];
+        NodeKids kd = m.kids[i];
+        nd.h1.parent = i == keep_root ? NIL : m.fwd[nd.h1.parent];
+        for (int c = 0; c < 25; ++c)
+            if (kd.c[c] != NIL) kd.c[c] = m.fwd[kd.c[c]];
+        m.stats[ni] = nd;
+        m.kids[ni] = kd;
+    }
+    s.root = 0;
+    s.hi = cnt;
+    s.node_count = cnt;  // tree.rs:290 count_subtree_nodes
+    s.status = SLOT_ACTIVE;
+}
+
+// Start a game in a slot (selfplay.rs:526-535). The caller has filled board, st, rng and the arena.
+template <int NW>
+AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     s.n_pos = 0;
     s.t_sims = s.t_nn = s.t_term = s.t_coll = 0;
     s.nv_gather = s.nv_backup = s.new_nodes = 0;
@@ -885,28 +1056,9 @@ AR_HD void start_game(Slot<NW>& s, const uint8_t* cost, const SearchCfg& cfg) {
     s.batch_active = 0;
     s.error = 0;
     s.remaining = cfg.n_sims;
-    make_root(s, cost, 0);
+    make_root(s, m);
     if (!s.single_search && st_over(s.board, s.st)) s.status = SLOT_DONE;  // while !check_game_over()
     else s.status = SLOT_ACTIVE;
 }
 
-}  // namespace ar
-
-// ---- arena growth ------------------------------------------------------------------------------
-// A stalled slot (gather_batch / advance_or_reinit found no room) is moved by the host runtime
-// into a bigger arena: the subtree it asked to keep is copied to the front of the new arena.
-namespace ar {
-template <int NW>
-AR_HD void migrate_slot(Slot<NW>& s, NodeStats* new_stats, NodeKids* new_kids, uint32_t new_cap) {
-    const uint32_t cnt =
-        copy_subtree(s.stats, s.kids, s.pending_root, new_stats, new_kids, 0, s.frames, s.max_depth, s.error);
-    s.stats = new_stats;
-    s.kids = new_kids;
-    s.cap = new_cap;
-    s.root = 0;
-    s.lo = 0;
-    s.hi = cnt;
-    s.node_count = cnt;
-    s.status = SLOT_ACTIVE;
-}
 }  // namespace ar

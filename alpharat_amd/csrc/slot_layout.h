@@ -7,7 +7,7 @@
 namespace ar {
 
 struct SlotLayout {
-    size_t proc_off, coll_off, levels_off, frames_off, ev_off, leaf_off, pos_off, total;
+    size_t proc_off, coll_off, levels_off, ev_off, leaf_off, pos_off, total;
     uint32_t coll_cap, max_depth;
 };
 
@@ -25,8 +25,6 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     off = align_up(off + sizeof(CollEntry) * L.coll_cap, 64);
     L.levels_off = off;
     off = align_up(off + sizeof(Level<NW>) * L.max_depth, 64);
-    L.frames_off = off;
-    off = align_up(off + sizeof(CopyFrame) * L.max_depth, 64);
     L.ev_off = off;
     off = align_up(off + sizeof(EvalOut) * cfg.batch_size, 64);
     L.leaf_off = off;
@@ -37,17 +35,27 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     return L;
 }
 
+// All of one game's addresses from the three bases the kernels receive as arguments
+// (arena_base, scratch_base, maze_pool): the pointers are derived from kernel arguments, never
+// loaded from memory, so the compiler addresses them as global memory.
 template <int NW>
-AR_HD void bind_scratch(Slot<NW>& s, unsigned char* base, const SlotLayout& L) {
-    s.proc = (ProcEntry*)(base + L.proc_off);
-    s.coll = (CollEntry*)(base + L.coll_off);
-    s.levels = (Level<NW>*)(base + L.levels_off);
-    s.frames = (CopyFrame*)(base + L.frames_off);
-    s.ev_local = (EvalOut*)(base + L.ev_off);
-    s.leaf_local = (State<NW>*)(base + L.leaf_off);
-    s.pos = (PosRec<NW>*)(base + L.pos_off);
-    s.coll_cap = L.coll_cap;
-    s.max_depth = L.max_depth;
+AR_HD Mem<NW> resolve_mem(const Slot<NW>& s, unsigned char* arena_base, unsigned char* scratch_base, uint32_t slot_id,
+                          const SlotLayout& L, const uint8_t* maze_pool) {
+    Mem<NW> m;
+    m.stats = (NodeStats*)(arena_base + s.stats_off);
+    m.kids = (NodeKids*)(arena_base + s.kids_off);
+    m.fwd = (uint32_t*)(arena_base + s.fwd_off);
+    unsigned char* base = scratch_base + (size_t)slot_id * L.total;
+    m.proc = (ProcEntry*)(base + L.proc_off);
+    m.coll = (CollEntry*)(base + L.coll_off);
+    m.levels = (Level<NW>*)(base + L.levels_off);
+    m.ev_local = (EvalOut*)(base + L.ev_off);
+    m.leaf_local = (State<NW>*)(base + L.leaf_off);
+    m.pos = (PosRec<NW>*)(base + L.pos_off);
+    m.cost = maze_pool + s.board.maze_off;
+    m.coll_cap = L.coll_cap;
+    m.max_depth = L.max_depth;
+    return m;
 }
 
 inline uint32_t next_pow2(uint32_t v) {
@@ -55,11 +63,14 @@ inline uint32_t next_pow2(uint32_t v) {
     while (p < v) p <<= 1;
     return p;
 }
-// first arena of a game: room for the kept subtree plus one search, twice over
+// first arena of a game: the kept subtree plus one search fits with room to spare; bigger trees
+// stall once and are moved to a doubled arena
 inline uint32_t initial_arena_nodes(const SearchCfg& cfg) {
     uint32_t want = 2 * (cfg.n_sims + 2 * cfg.batch_size) + 64;
     uint32_t p = next_pow2(want);
     return p < 256 ? 256 : p;
 }
+// bytes of one arena of `cap` nodes: [stats | kids | fwd]
+AR_HD size_t arena_bytes(uint32_t cap) { return (size_t)cap * (sizeof(NodeStats) + sizeof(NodeKids) + sizeof(uint32_t)); }
 
 }  // namespace ar

@@ -33,11 +33,16 @@ struct HsGame {
 struct HsRun {
     Slot<4> slot;
     std::vector<unsigned char> scratch;
-    std::vector<NodeStats> stats;
-    std::vector<NodeKids> kids;
+    std::vector<unsigned char> arena;  // [stats | kids | fwd]
     std::vector<uint8_t> cost;
     SearchCfg cfg;
+    SlotLayout L;
     uint32_t grows = 0;
+    Mem<4> mem() { return resolve_mem<4>(slot, arena.data(), scratch.data(), 0, L, cost.data()); }
+    const Mem<4> cmem() const {
+        return resolve_mem<4>(slot, const_cast<unsigned char*>(arena.data()),
+                              const_cast<unsigned char*>(scratch.data()), 0, L, cost.data());
+    }
 };
 
 static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
@@ -57,17 +62,25 @@ static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
     return s;
 }
 
+static void set_arena(HsRun* r, uint32_t cap) {
+    r->slot.cap = cap;
+    r->slot.stats_off = 0;
+    r->slot.kids_off = (long long)((size_t)cap * sizeof(NodeStats));
+    r->slot.fwd_off = r->slot.kids_off + (long long)((size_t)cap * sizeof(NodeKids));
+}
+
+// what the runtime does for a stalled slot: a doubled arena, live nodes copied across unchanged
 static void grow(HsRun* r) {
-    uint32_t want = r->slot.need_nodes;
     uint32_t ncap = r->slot.cap * 2;
-    while (ncap < want) ncap *= 2;
-    std::vector<NodeStats> ns(ncap);
-    std::vector<NodeKids> nk(ncap);
-    migrate_slot(r->slot, ns.data(), nk.data(), ncap);
-    r->stats.swap(ns);
-    r->kids.swap(nk);
-    r->slot.stats = r->stats.data();
-    r->slot.kids = r->kids.data();
+    while (ncap < r->slot.need_nodes) ncap *= 2;
+    std::vector<unsigned char> na(arena_bytes(ncap) + 256);
+    const uint32_t hi = r->slot.hi, ocap = r->slot.cap;
+    std::memcpy(na.data(), r->arena.data(), (size_t)hi * sizeof(NodeStats));
+    std::memcpy(na.data() + (size_t)ncap * sizeof(NodeStats), r->arena.data() + (size_t)ocap * sizeof(NodeStats),
+                (size_t)hi * sizeof(NodeKids));
+    r->arena.swap(na);
+    set_arena(r, ncap);
+    r->slot.status = SLOT_ACTIVE;
     r->grows += 1;
 }
 
@@ -79,17 +92,13 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
     r->cfg = to_cfg(c, n_sims, batch);
     const int hw = g->width * g->height;
     r->cost.assign(g->cost, g->cost + hw * 4);
-    SlotLayout L = make_layout<4>(r->cfg, g->max_turns);
-    r->scratch.assign(L.total, 0);
+    r->L = make_layout<4>(r->cfg, g->max_turns);
+    r->scratch.assign(r->L.total, 0);
     uint32_t cap = arena_nodes ? arena_nodes : initial_arena_nodes(r->cfg);
-    r->stats.resize(cap);
-    r->kids.resize(cap);
+    r->arena.assign(arena_bytes(cap) + 256, 0);
     Slot<4>& s = r->slot;
     std::memset(&s, 0, sizeof s);
-    bind_scratch(s, r->scratch.data(), L);
-    s.stats = r->stats.data();
-    s.kids = r->kids.data();
-    s.cap = cap;
+    set_arena(r, cap);
     s.board.width = g->width;
     s.board.height = g->height;
     s.board.max_turns = g->max_turns;
@@ -112,30 +121,32 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
     s.st.m2 = g->p2_mud;
     rng_seed(s.rng, seed);
     s.single_search = single;
-    const uint8_t* cost = r->cost.data();
-    start_game(s, cost, r->cfg);
-    GatherCtx cx;
-    cx.cost = cost;
-    cx.eval_mode = eval_mode == 0 ? EVAL_UNIFORM : EVAL_STORE;
+    start_game(s, r->mem(), r->cfg);
+    const int mode = eval_mode == 0 ? EVAL_UNIFORM : EVAL_STORE;
     std::vector<EvalOut> ev(batch);
-    while (s.status == SLOT_ACTIVE || s.status == SLOT_STALL) {
+    while (s.status == SLOT_ACTIVE || s.status == SLOT_STALL || s.status == SLOT_ADVANCE) {
         if (s.status == SLOT_STALL) {
             grow(r);
             continue;
         }
-        if (!gather_batch(s, cx, r->cfg)) continue;
-        const EvalOut* evp = s.ev_local;
+        Mem<4> m = r->mem();
+        if (s.status == SLOT_ADVANCE) {
+            advance_tree_scalar(s, m);
+            continue;
+        }
+        if (!gather_machine(s, m, r->cfg, mode)) continue;
+        const EvalOut* evp = m.ev_local;
         if (eval_mode != 0) {
             for (uint32_t j = 0; j < s.b_nn; ++j) {
-                const State<4>& lf = s.leaf_local[j];
-                uniform_prior(eff_actions(cost, lf.p1, lf.m1), ev[j].p1);
-                uniform_prior(eff_actions(cost, lf.p2, lf.m2), ev[j].p2);
+                const State<4>& lf = m.leaf_local[j];
+                uniform_prior(eff_actions(m.cost, lf.p1, lf.m1), ev[j].p1);
+                uniform_prior(eff_actions(m.cost, lf.p2, lf.m2), ev[j].p2);
                 ev[j].v1 = v1;
                 ev[j].v2 = v2;
             }
             evp = ev.data();
         }
-        if (backup_batch(s, r->cfg, evp, &g_zig)) finish_move(s, cost, r->cfg);
+        if (backup_machine(s, m, r->cfg, evp, &g_zig)) finish_move(s, m, r->cfg);
     }
     return r;
 }
@@ -189,7 +200,7 @@ void hs_positions(const void* p, int32_t* ints, float* floats, uint8_t* masks) {
     const Slot<4>& s = r->slot;
     int w = s.board.width, hw = s.board.width * s.board.height;
     for (uint32_t i = 0; i < s.n_pos; ++i) {
-        const PosRec<4>& q = s.pos[i];
+        const PosRec<4>& q = r->cmem().pos[i];
         int32_t* I = ints + (size_t)i * 9;
         I[0] = q.st.p1 % w;
         I[1] = q.st.p1 / w;
@@ -222,6 +233,7 @@ void hs_last(const void* p, float* F34, uint32_t cnt[4]) {
 uint32_t hs_tree_dump(const void* p, uint32_t* out, uint32_t max_nodes) {
     const HsRun* r = (const HsRun*)p;
     const Slot<4>& s = r->slot;
+    const Mem<4> m = r->cmem();
     struct It {
         uint32_t id, depth;
     };
@@ -230,22 +242,22 @@ uint32_t hs_tree_dump(const void* p, uint32_t* out, uint32_t max_nodes) {
     while (!st.empty()) {
         It it = st.back();
         st.pop_back();
-        const NodeStats& n = s.stats[it.id];
+        const NodeStats& n = m.stats[it.id];
         if (count < max_nodes) {
             uint32_t* o = out + (size_t)count * 43;
             o[0] = it.depth;
-            o[1] = it.depth ? n.po[0] : 0;
-            o[2] = it.depth ? n.po[1] : 0;
-            o[3] = n.visits;
-            o[4] = n.nif;
-            o[5] = n.terminal;
-            o[6] = n.n[0];
-            o[7] = n.n[1];
-            o[8] = f32_to_bits(n.v1);
-            o[9] = f32_to_bits(n.v2);
-            o[10] = f32_to_bits(n.scale);
-            o[11] = f32_to_bits(it.depth ? n.r1 : 0.0f);
-            o[12] = f32_to_bits(it.depth ? n.r2 : 0.0f);
+            o[1] = it.depth ? meta_po(n.h2.meta, 0) : 0;
+            o[2] = it.depth ? meta_po(n.h2.meta, 1) : 0;
+            o[3] = n.h0.visits;
+            o[4] = n.h0.nif;
+            o[5] = n.h2.terminal;
+            o[6] = meta_n(n.h2.meta, 0);
+            o[7] = meta_n(n.h2.meta, 1);
+            o[8] = f32_to_bits(n.h0.v1);
+            o[9] = f32_to_bits(n.h0.v2);
+            o[10] = f32_to_bits(n.h1.scale);
+            o[11] = f32_to_bits(it.depth ? n.h1.r1 : 0.0f);
+            o[12] = f32_to_bits(it.depth ? n.h1.r2 : 0.0f);
             for (int i = 0; i < 5; ++i) {
                 o[13 + i * 3] = f32_to_bits(n.e[0][i].prior);
                 o[14 + i * 3] = f32_to_bits(n.e[0][i].q);
@@ -257,7 +269,7 @@ uint32_t hs_tree_dump(const void* p, uint32_t* out, uint32_t max_nodes) {
         }
         ++count;
         for (int i = 24; i >= 0; --i)
-            if (s.kids[it.id].c[i] != NIL) st.push_back({s.kids[it.id].c[i], it.depth + 1});
+            if (m.kids[it.id].c[i] != NIL) st.push_back({m.kids[it.id].c[i], it.depth + 1});
     }
     return count;
 }

@@ -79,7 +79,7 @@ def test_arena_growth_keeps_results():
     cfg = O.make_config(**TUNED)
     want = O.play_game(g, cfg, 500, 16, 5)
     got = H.run(g, 50, cfg, 500, 16, 5, arena_nodes=64)
-    assert got["grows"] >= 2
+    assert got["grows"] >= 1
     _same_game(want, got)
 
 
