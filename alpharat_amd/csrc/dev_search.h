@@ -412,8 +412,31 @@ enum {
     G_PICK = 0,   // start one pick_nodes_to_extend call (or finish the gather)
     G_ALLOC = 1,  // one allocation step at the current node
     G_CHILD = 2,  // process the next child slot that received visits (or pop)
-    G_DONE = 3
+    G_ENTER = 3,  // load a node for expansion and set up its allocation state
+    G_DONE = 4
 };
+
+// Which state the wavefront runs next: the one most lanes are waiting in. Lanes in other states sit
+// the round out, so every executed instruction serves as many lanes as possible; a lane's own
+// sequence of states -- and therefore its result -- does not depend on the election.
+AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_state) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t best = done_state;
+    int best_count = 0;
+    for (uint32_t st = 0; st < n_states; ++st) {
+        const int c = __popcll(__ballot(state == st));
+        if (c > best_count) {
+            best_count = c;
+            best = st;
+        }
+    }
+    return best;
+#else
+    (void)n_states;
+    (void)done_state;
+    return state;
+#endif
+}
 
 template <int NW>
 AR_HD void emit_proc(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode, uint32_t node, uint32_t kind,
@@ -494,9 +517,12 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
         h2.ns[j] = h2.add[j] = h2.nif0[j] = 0;
     }
 
-    while (state != G_DONE) {
-        uint32_t enter = NIL, enter_budget = 0;  // node to load for expansion at the end of this step
-        bool enter_root = false;
+    uint32_t enter = NIL, enter_budget = 0;  // node to load for expansion (G_ENTER)
+    bool enter_root = false;
+    for (;;) {
+        const uint32_t run = elect_state(state, G_DONE, G_DONE);
+        if (run == G_DONE) break;
+        if (state != run) continue;
         if (state == G_ALLOC) {
             // search.rs:775-798, one step
             uint32_t b1, b2, c1, c2;
@@ -599,9 +625,11 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
                     depth += 1;
                     enter = child;
                     enter_budget = k;
+                    enter_root = false;
+                    state = G_ENTER;
                 }
             }
-        } else {  // G_PICK
+        } else if (state == G_PICK) {
             if (have_pick) {
                 s.b_coll += pick_mv;
                 left -= (long long)pick_mv;
@@ -640,10 +668,10 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
                     enter = root;
                     enter_budget = budget;
                     enter_root = true;
+                    state = G_ENTER;
                 }
             }
-        }
-        if (enter != NIL) {
+        } else {  // G_ENTER
             // load the node for expansion: everything select needs arrives in one round trip
             const NodeStats& N = m.stats[enter];
             Edge e1[5], e2[5];
@@ -717,7 +745,10 @@ AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, c
     uint32_t i = 0, j = 0;  // proc index, eval index
     uint32_t parent = 0, po = 0, mv = 0;
     float v1 = 0.0f, v2 = 0.0f, cr1 = 0.0f, cr2 = 0.0f;
-    while (state != B_DONE) {
+    for (;;) {
+        const uint32_t run = elect_state(state, B_DONE, B_DONE);
+        if (run == B_DONE) break;
+        if (state != run) continue;
         if (state == B_LEVEL) {
             // search.rs:834-851 one ancestor: everything of the parent arrives in one round trip
             NodeStats& P = m.stats[parent];
