@@ -58,7 +58,7 @@ struct GameInit {
     uint32_t game_index;
     uint32_t slot;
     uint32_t single;
-    uint32_t pad;
+    uint32_t reset_arena;  // 1: the slot's grown arena was released, go back to its pool share
 };
 
 template <int NW>
@@ -84,7 +84,7 @@ __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t
     if (i >= n) return;
     const GameInit<NW> gi = init[i];
     Slot<NW> s = slots[gi.slot];
-    if (s.cap == 0) {  // first use of this slot: its share of the arena pool
+    if (s.cap == 0 || gi.reset_arena) {  // first use of this slot (or after a release): its share of the pool
         const long long base = (long long)gi.slot * (long long)arena_bytes(B.cap0);
         s.cap = B.cap0;
         s.stats_off = base;
@@ -588,7 +588,7 @@ struct Engine {
     PinBuf<StallInfo> h_stall;
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
-    std::vector<void*> grown;  // arenas allocated after a stall, freed with the engine
+    std::vector<void*> slot_grown;  // per slot: the arena allocated after a stall (nullptr = pool share)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double device_ms = 0.0;
     uint64_t steps = 0;
@@ -598,7 +598,8 @@ struct Engine {
 
     ~Engine() {
         if (stream) hipStreamSynchronize(stream);
-        for (void* p : grown) hipFree(p);
+        for (void* p : slot_grown)
+            if (p) hipFree(p);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (stream) hipStreamDestroy(stream);
@@ -626,6 +627,7 @@ struct Engine {
         HIP_TRY(hipEventCreate(&ev1));
         L = make_layout<NW>(cfg, max_turns);
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
+        slot_grown.assign(S, nullptr);
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
@@ -663,8 +665,16 @@ struct Engine {
 
     uint32_t grid(uint32_t n) const { return (n + 63) / 64; }
 
-    int start_games(const std::vector<GameInit<NW>>& games) {
+    int start_games(std::vector<GameInit<NW>>& games) {
         if (games.empty()) return AR_OK;
+        for (GameInit<NW>& g : games) {  // a new game starts from the slot's pool share again
+            g.reset_arena = 0;
+            if (slot_grown[g.slot]) {
+                hipFree(slot_grown[g.slot]);  // the slot was drained: no kernel touches that arena any more
+                slot_grown[g.slot] = nullptr;
+                g.reset_arena = 1;
+            }
+        }
         HIP_TRY(hipMemcpyAsync(init.p, games.data(), sizeof(GameInit<NW>) * games.size(), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_init_games<NW>, dim3(grid((uint32_t)games.size())), dim3(64), 0, stream, slots.p, init.p,
                            (uint32_t)games.size(), bases(), cfg);
@@ -740,6 +750,7 @@ struct Engine {
         HIP_TRY(hipMemcpyAsync(h_stall.p, stall_info.p, sizeof(StallInfo) * n_stall, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         std::vector<GrowReq> reqs(n_stall);
+        std::vector<void*> old_arenas;
         for (uint32_t i = 0; i < n_stall; ++i) {
             const StallInfo& si = h_stall.p[i];
             uint32_t ncap = si.cap * 2;
@@ -748,7 +759,8 @@ struct Engine {
             if (hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess)
                 return fail(AR_E_NOMEM, "out of device memory while growing a tree arena to " + std::to_string(ncap) +
                                             " nodes");
-            grown.push_back(na);
+            if (slot_grown[si.slot]) old_arenas.push_back(slot_grown[si.slot]);
+            slot_grown[si.slot] = na;
             GrowReq r;
             r.slot = si.slot;
             r.cap = ncap;
@@ -765,6 +777,7 @@ struct Engine {
         hipLaunchKernelGGL(k_apply_grow<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
+        for (void* p : old_arenas) hipFree(p);
         grows += n_stall;
         return AR_OK;
     }
