@@ -112,6 +112,8 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
     if (slots[i].status != SLOT_ACTIVE) return;
     Slot<NW> s = slots[i];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    // (fused_machine -- lanes free-running across batch boundaries -- measured slower: it spreads the
+    // wavefront over twice as many states per round)
     for (int it = 0; it < iters; ++it) {
         if (s.status != SLOT_ACTIVE) break;
         if (!gather_machine(s, m, cfg, EVAL_UNIFORM)) break;
@@ -1334,6 +1336,16 @@ int ar_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return fail(AR_E_DEVICE, "hipGetDeviceCount failed (no HIP device?)");
     return n;
 }
+
+#if defined(AR_STATS)
+int ar_debug_round_stats(unsigned long long* out32) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ar::g_round_stats), sizeof(unsigned long long) * 32));
+    unsigned long long z[32] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ar::g_round_stats), z, sizeof z));
+    return AR_OK;
+}
+#endif
 
 int ar_device_sync(int device) {
     int dev = 0;

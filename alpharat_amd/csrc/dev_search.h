@@ -410,7 +410,7 @@ AR_HD int lowest_bit(uint32_t m) {
 // ---- gather: search.rs:961-999 (outer loop) + 576-738 (pick_nodes_to_extend) + 742-817 ---------
 enum {
     G_PICK = 0,   // start one pick_nodes_to_extend call (or finish the gather)
-    G_ALLOC = 1,  // one allocation step at the current node
+    G_ALLOC = 1,  // (unused: the allocation loop runs inside G_ENTER)
     G_CHILD = 2,  // process the next child slot that received visits (or pop)
     G_ENTER = 3,  // load a node for expansion and set up its allocation state
     G_DONE = 4
@@ -419,7 +419,10 @@ enum {
 // Which state the wavefront runs next: the one most lanes are waiting in. Lanes in other states sit
 // the round out, so every executed instruction serves as many lanes as possible; a lane's own
 // sequence of states -- and therefore its result -- does not depend on the election.
-AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_state) {
+#if defined(AR_STATS) && defined(__HIPCC__)
+__device__ unsigned long long g_round_stats[32];  // [machine*16 + state*2 + {rounds, lanes}] , [30] alive, [31] rounds
+#endif
+AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_state, uint32_t machine = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t best = done_state;
     int best_count = 0;
@@ -430,6 +433,18 @@ AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_stat
             best = st;
         }
     }
+#if defined(AR_STATS)
+    if (best != done_state) {
+        const int alive = __popcll(__ballot(state != done_state));
+        if (__popcll(__ballot(1) & ((1ULL << (threadIdx.x & 63)) - 1ULL)) == 0) {
+            atomicAdd(&g_round_stats[machine * 12 + best * 2], 1ULL);
+            atomicAdd(&g_round_stats[machine * 12 + best * 2 + 1], (unsigned long long)best_count);
+            atomicAdd(&g_round_stats[30], (unsigned long long)alive);
+            atomicAdd(&g_round_stats[31], 1ULL);
+        }
+    }
+#endif
+    (void)machine;
     return best;
 #else
     (void)n_states;
@@ -480,51 +495,168 @@ AR_HD void emit_coll(Slot<NW>& s, const Mem<NW>& m, uint32_t node, uint32_t mv, 
     s.n_coll += 1;
 }
 
-// Returns false when the arena cannot take a full batch (the slot stalls untouched).
+// ---- per-lane gather state (registers) ---------------------------------------------------------
 template <int NW>
-AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode) {
-    const uint32_t batch = s.remaining < cfg.batch_size ? s.remaining : cfg.batch_size;
-    if (s.hi + batch > s.cap) {
+struct GatherLane {
+    uint32_t state;
+    uint32_t batch;        // productive entries wanted this batch
+    long long left;        // collision budget left (search.rs:970)
+    uint32_t depth;        // levels kept on the stack below the current node
+    uint32_t node;         // current node
+    uint32_t mask;         // child slots of the current node still to process
+    uint32_t omap0, omap1;
+    uint32_t vtp[13];      // 25 x u16 visits allocated to the child slots
+    uint32_t pick_mv;      // collision multivisits of the running pick_nodes_to_extend call
+    uint32_t enter, enter_budget;
+    bool have_pick, enter_root;
+    int eval_mode;
+    State<NW> work;        // position at the current node
+};
+
+// Starts one simulate_batch. Returns false when the arena cannot take a full batch (the slot
+// stalls untouched and the host moves it to a bigger arena).
+template <int NW>
+AR_HD bool gather_begin(GatherLane<NW>& g, Slot<NW>& s, const SearchCfg& cfg, int eval_mode) {
+    g.state = G_DONE;
+    g.batch = s.remaining < cfg.batch_size ? s.remaining : cfg.batch_size;
+    if (s.hi + g.batch > s.cap) {
         s.status = SLOT_STALL;
         s.need_nodes = s.hi + cfg.n_sims + 2 * cfg.batch_size;
         return false;
     }
-    long long left = (long long)(int32_t)collisions_left(s.node_count, cfg);
+    g.left = (long long)(int32_t)collisions_left(s.node_count, cfg);
     s.n_proc = 0;
     s.n_coll = 0;
     s.b_nn = 0;
     s.b_term = 0;
     s.b_coll = 0;
+    g.state = G_PICK;
+    g.depth = 0;
+    g.node = 0;
+    g.mask = 0;
+    g.omap0 = g.omap1 = 0;
+    for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
+    g.pick_mv = 0;
+    g.enter = NIL;
+    g.enter_budget = 0;
+    g.have_pick = false;
+    g.enter_root = false;
+    g.eval_mode = eval_mode;
+    g.work = s.st;
+    return true;
+}
 
-    uint32_t state = G_PICK;
-    uint32_t depth = 0;      // levels on the stack below the current one
-    uint32_t node = 0;       // current node
-    uint32_t remaining = 0;  // visits still to allocate at the current node
-    uint32_t mask = 0;       // child slots of the current node still to process
-    uint32_t omap0 = 0, omap1 = 0;
-    uint32_t vtp[13];
-    uint32_t pick_mv = 0;
-    bool have_pick = false;
-    HalfAlloc h1, h2;
-    State<NW> work = s.st;
-    for (int j = 0; j < 13; ++j) vtp[j] = 0;
-    h1.n = h2.n = 0;
-    h1.forced = h2.forced = 0;
-    for (int j = 0; j < 5; ++j) {
-        h1.score[j] = h1.util[j] = h1.num[j] = 0.0f;
-        h2.score[j] = h2.util[j] = h2.num[j] = 0.0f;
-        h1.ns[j] = h1.add[j] = h1.nif0[j] = 0;
-        h2.ns[j] = h2.add[j] = h2.nif0[j] = 0;
-    }
-
-    uint32_t enter = NIL, enter_budget = 0;  // node to load for expansion (G_ENTER)
-    bool enter_root = false;
-    for (;;) {
-        const uint32_t run = elect_state(state, G_DONE, G_DONE);
-        if (run == G_DONE) break;
-        if (state != run) continue;
-        if (state == G_ALLOC) {
-            // search.rs:775-798, one step
+// One round of the lane's current gather state.
+template <int NW>
+AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
+    if (g.state == G_CHILD) {
+        if (g.mask == 0) {
+            // level exhausted: backtrack (search.rs:728-734)
+            if (g.depth == 0) {
+                g.state = G_PICK;
+            } else {
+                g.depth -= 1;
+                const Level<NW>& L = m.levels[g.depth];
+                g.node = L.node;
+                g.mask = L.mask;
+                g.omap0 = L.omap[0];
+                g.omap1 = L.omap[1];
+                for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
+                g.work = L.saved;
+            }
+            return;
+        }
+        const uint32_t idx = (uint32_t)lowest_bit(g.mask);
+        g.mask &= g.mask - 1;
+        const uint32_t k = vtp_get(g.vtp, idx);
+        const uint32_t o1 = idx / 5, o2 = idx % 5;
+        const State<NW> before = g.work;
+        float r1, r2;
+        st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
+        uint32_t child = m.kids[g.node].c[idx];
+        bool leaf_path = true, ok = true;
+        uint32_t c_visits = 0, c_nif = 0, c_term = 0;
+        if (child == NIL) {
+            if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
+                s.error = 3;
+                ok = false;
+            } else {
+                child = s.hi++;
+                init_shell(m.stats[child], m.kids[child], eff_actions(m.cost, g.work.p1, g.work.m1),
+                           eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
+                m.kids[g.node].c[idx] = child;
+                s.node_count += 1;
+                s.new_nodes += 1;
+            }
+        } else {
+            const NodeH0 a = m.stats[child].h0;
+            c_visits = a.visits;
+            c_nif = a.nif;
+            c_term = m.stats[child].h2.terminal;
+            leaf_path = c_visits == 0 || c_term != 0;
+        }
+        if (!ok) {
+            g.work = before;
+        } else if (leaf_path) {
+            // search.rs:675-706
+            if (!(c_visits == 0 && c_nif > 0)) {  // try_start_score_update
+                m.stats[child].h0.nif = c_nif + 1;
+                if (c_term != 0 || st_over(s.board, g.work)) {
+                    if (c_visits == 0) m.stats[child].h2.terminal = 1;
+                    emit_proc(s, m, cfg, g.eval_mode, child, PROC_TERMINAL, g.work);
+                } else {
+                    emit_proc(s, m, cfg, g.eval_mode, child, PROC_EVAL, g.work);
+                }
+                if (k > 1) emit_coll(s, m, child, k - 1, g.pick_mv);
+            } else {
+                emit_coll(s, m, child, k, g.pick_mv);
+            }
+            g.work = before;
+        } else if (g.depth >= m.max_depth) {
+            s.error = 4;
+            g.work = before;
+        } else {
+            // search.rs:707-725: interior child, descend with k visits
+            m.stats[child].h0.nif = c_nif + k;
+            if (g.mask != 0) {  // children of this node still wait: keep the level for the way back
+                Level<NW>& L = m.levels[g.depth];
+                L.node = g.node;
+                L.mask = g.mask;
+                L.omap[0] = g.omap0;
+                L.omap[1] = g.omap1;
+                for (int j = 0; j < 13; ++j) L.vtp[j] = g.vtp[j];
+                L.saved = before;
+                g.depth += 1;
+            }
+            g.enter = child;
+            g.enter_budget = k;
+            g.enter_root = false;
+            g.state = G_ENTER;
+        }
+    } else if (g.state == G_ENTER) {
+        // load the node for expansion: everything select needs arrives in one round trip
+        const NodeStats& N = m.stats[g.enter];
+        Edge e1[5], e2[5];
+        for (int i = 0; i < 5; ++i) {
+            e1[i] = N.e[0][i];
+            e2[i] = N.e[1][i];
+        }
+        const NodeH0 a = N.h0;
+        const NodeH1 b = N.h1;
+        const NodeH2 c = N.h2;
+        const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
+        HalfAlloc h1, h2;
+        half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, g.enter_root);
+        half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, g.enter_root);
+        g.node = g.enter;
+        g.omap0 = c.omap[0];
+        g.omap1 = c.omap[1];
+        g.mask = 0;
+        for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
+        s.nv_gather += 1;
+        // search.rs:775-798: split the visits over child pairs (no memory traffic in this loop)
+        uint32_t remaining = g.enter_budget;
+        while (remaining > 0) {
             uint32_t b1, b2, c1, c2;
             half_best(h1, s.rng, b1, c1);
             half_best(h2, s.rng, b2, c2);
@@ -533,170 +665,77 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
             if (c2 < k) k = c2;
             if (k < 1) k = 1;
             const uint32_t flat = b1 * 5 + b2;
-            vtp_add(vtp, flat, k);
-            mask |= 1u << flat;
+            vtp_add(g.vtp, flat, k);
+            g.mask |= 1u << flat;
             half_take(h1, b1, k);
             half_take(h2, b2, k);
             remaining -= k;
-            if (remaining == 0) {
-                // search.rs:800-814: write the virtual-loss deltas back
-                NodeStats& N = m.stats[node];
-                for (uint32_t i = 0; i < 5; ++i) {
-                    if (h1.add[i]) N.e[0][i].nif = h1.nif0[i] + h1.add[i];
-                    if (h2.add[i]) N.e[1][i].nif = h2.nif0[i] + h2.add[i];
-                }
-                state = G_CHILD;
-            }
-        } else if (state == G_CHILD) {
-            if (mask == 0) {
-                // level exhausted: backtrack (search.rs:728-734)
-                if (depth == 0) {
-                    state = G_PICK;
+        }
+        // search.rs:800-814: write the virtual-loss deltas back
+        NodeStats& W = m.stats[g.node];
+        for (uint32_t i = 0; i < 5; ++i) {
+            if (h1.add[i]) W.e[0][i].nif = h1.nif0[i] + h1.add[i];
+            if (h2.add[i]) W.e[1][i].nif = h2.nif0[i] + h2.add[i];
+        }
+        g.state = G_CHILD;
+    } else if (g.state == G_PICK) {
+        // search.rs:981-999 outer gather loop around pick_nodes_to_extend
+        if (g.have_pick) {
+            s.b_coll += g.pick_mv;
+            g.left -= (long long)g.pick_mv;
+            g.have_pick = false;
+        }
+        if (!(s.n_proc < g.batch && g.left > 0)) {
+            g.state = G_DONE;
+            s.batch_active = 1;
+            return;
+        }
+        uint32_t budget = (uint32_t)g.left;
+        if (g.batch - s.n_proc < budget) budget = g.batch - s.n_proc;
+        g.pick_mv = 0;
+        g.have_pick = true;
+        g.work = s.st;
+        g.depth = 0;
+        const uint32_t root = s.root;
+        const NodeH0 a = m.stats[root].h0;
+        const uint32_t term = m.stats[root].h2.terminal;
+        if (a.visits == 0 || term) {
+            // search.rs:591-636: unvisited or terminal root
+            const bool claim = !(a.visits == 0 && a.nif > 0);
+            if (claim) {
+                m.stats[root].h0.nif = a.nif + 1;
+                if (term || st_over(s.board, g.work)) {
+                    if (a.visits == 0) m.stats[root].h2.terminal = 1;
+                    emit_proc(s, m, cfg, g.eval_mode, root, PROC_TERMINAL, g.work);
                 } else {
-                    depth -= 1;
-                    const Level<NW>& L = m.levels[depth];
-                    node = L.node;
-                    mask = L.mask;
-                    omap0 = L.omap[0];
-                    omap1 = L.omap[1];
-                    for (int j = 0; j < 13; ++j) vtp[j] = L.vtp[j];
-                    work = L.saved;
+                    emit_proc(s, m, cfg, g.eval_mode, root, PROC_EVAL, g.work);
                 }
+                if (budget > 1) emit_coll(s, m, root, budget - 1, g.pick_mv);
             } else {
-                const uint32_t idx = (uint32_t)lowest_bit(mask);
-                mask &= mask - 1;
-                const uint32_t k = vtp_get(vtp, idx);
-                const uint32_t o1 = idx / 5, o2 = idx % 5;
-                const State<NW> before = work;
-                float r1, r2;
-                st_step(s.board, m.cost, work, outcome_action(omap0, o1), outcome_action(omap1, o2), r1, r2);
-                uint32_t child = m.kids[node].c[idx];
-                bool leaf_path = true, ok = true;
-                uint32_t c_visits = 0, c_nif = 0, c_term = 0;
-                if (child == NIL) {
-                    if (s.hi >= s.cap) {  // excluded by the capacity check above
-                        s.error = 3;
-                        ok = false;
-                    } else {
-                        child = s.hi++;
-                        init_shell(m.stats[child], m.kids[child], eff_actions(m.cost, work.p1, work.m1),
-                                   eff_actions(m.cost, work.p2, work.m2), work.remaining, node, o1, o2, r1, r2);
-                        m.kids[node].c[idx] = child;
-                        s.node_count += 1;
-                        s.new_nodes += 1;
-                    }
-                } else {
-                    const NodeH0 a = m.stats[child].h0;
-                    c_visits = a.visits;
-                    c_nif = a.nif;
-                    c_term = m.stats[child].h2.terminal;
-                    leaf_path = c_visits == 0 || c_term != 0;
-                }
-                if (!ok) {
-                    work = before;
-                } else if (leaf_path) {
-                    // search.rs:675-706
-                    if (!(c_visits == 0 && c_nif > 0)) {  // try_start_score_update
-                        m.stats[child].h0.nif = c_nif + 1;
-                        if (c_term != 0 || st_over(s.board, work)) {
-                            if (c_visits == 0) m.stats[child].h2.terminal = 1;
-                            emit_proc(s, m, cfg, eval_mode, child, PROC_TERMINAL, work);
-                        } else {
-                            emit_proc(s, m, cfg, eval_mode, child, PROC_EVAL, work);
-                        }
-                        if (k > 1) emit_coll(s, m, child, k - 1, pick_mv);
-                    } else {
-                        emit_coll(s, m, child, k, pick_mv);
-                    }
-                    work = before;
-                } else if (depth >= m.max_depth) {
-                    s.error = 4;
-                    work = before;
-                } else {
-                    // search.rs:707-725: interior child, descend with k visits
-                    m.stats[child].h0.nif = c_nif + k;
-                    Level<NW>& L = m.levels[depth];
-                    L.node = node;
-                    L.mask = mask;
-                    L.omap[0] = omap0;
-                    L.omap[1] = omap1;
-                    for (int j = 0; j < 13; ++j) L.vtp[j] = vtp[j];
-                    L.saved = before;
-                    depth += 1;
-                    enter = child;
-                    enter_budget = k;
-                    enter_root = false;
-                    state = G_ENTER;
-                }
+                emit_coll(s, m, root, budget, g.pick_mv);
             }
-        } else if (state == G_PICK) {
-            if (have_pick) {
-                s.b_coll += pick_mv;
-                left -= (long long)pick_mv;
-                have_pick = false;
-            }
-            if (!(s.n_proc < batch && left > 0)) {
-                state = G_DONE;
-            } else {
-                uint32_t budget = (uint32_t)left;
-                if (batch - s.n_proc < budget) budget = batch - s.n_proc;
-                pick_mv = 0;
-                have_pick = true;
-                work = s.st;
-                depth = 0;
-                const uint32_t root = s.root;
-                const NodeH0 a = m.stats[root].h0;
-                const uint32_t term = m.stats[root].h2.terminal;
-                if (a.visits == 0 || term) {
-                    // search.rs:591-636: unvisited or terminal root
-                    const bool claim = !(a.visits == 0 && a.nif > 0);
-                    if (claim) {
-                        m.stats[root].h0.nif = a.nif + 1;
-                        if (term || st_over(s.board, work)) {
-                            if (a.visits == 0) m.stats[root].h2.terminal = 1;
-                            emit_proc(s, m, cfg, eval_mode, root, PROC_TERMINAL, work);
-                        } else {
-                            emit_proc(s, m, cfg, eval_mode, root, PROC_EVAL, work);
-                        }
-                        if (budget > 1) emit_coll(s, m, root, budget - 1, pick_mv);
-                    } else {
-                        emit_coll(s, m, root, budget, pick_mv);
-                    }
-                    // stay in G_PICK: the next iteration accounts for this pick
-                } else {
-                    m.stats[root].h0.nif = a.nif + budget;  // search.rs:639
-                    enter = root;
-                    enter_budget = budget;
-                    enter_root = true;
-                    state = G_ENTER;
-                }
-            }
-        } else {  // G_ENTER
-            // load the node for expansion: everything select needs arrives in one round trip
-            const NodeStats& N = m.stats[enter];
-            Edge e1[5], e2[5];
-            for (int i = 0; i < 5; ++i) {
-                e1[i] = N.e[0][i];
-                e2[i] = N.e[1][i];
-            }
-            const NodeH0 a = N.h0;
-            const NodeH1 b = N.h1;
-            const NodeH2 c = N.h2;
-            const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
-            half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, enter_root);
-            half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, enter_root);
-            node = enter;
-            remaining = enter_budget;
-            omap0 = c.omap[0];
-            omap1 = c.omap[1];
-            mask = 0;
-            for (int j = 0; j < 13; ++j) vtp[j] = 0;
-            s.nv_gather += 1;
-            state = G_ALLOC;
+            // stay in G_PICK: the next round accounts for this pick
+        } else {
+            m.stats[root].h0.nif = a.nif + budget;  // search.rs:639
+            g.enter = root;
+            g.enter_budget = budget;
+            g.enter_root = true;
+            g.state = G_ENTER;
         }
     }
-    s.batch_active = 1;
-    return true;
+}
+
+// gather of one simulate_batch for every lane of the wavefront (split kernels: evaluator outside)
+template <int NW>
+AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode) {
+    GatherLane<NW> g;
+    const bool ok = gather_begin(g, s, cfg, eval_mode);
+    for (;;) {
+        const uint32_t run = elect_state(g.state, G_DONE, G_DONE);
+        if (run == G_DONE) break;
+        if (g.state == run) gather_round(g, s, m, cfg);
+    }
+    return ok;
 }
 
 // ---- backup: search.rs:1027-1066 ---------------------------------------------------------------
@@ -738,107 +777,118 @@ AR_HD bool dirichlet_mix(float* prior, uint32_t n, float epsilon, float concentr
 
 enum { B_ENTRY = 0, B_LEVEL = 1, B_CANCEL = 2, B_CANCEL_LEVEL = 3, B_DONE = 4 };
 
-// `ev` holds b_nn results in gather order. Returns true when the search is complete.
+struct BackupLane {
+    uint32_t state;
+    uint32_t i, j;  // proc / collision index, eval index
+    uint32_t parent, po, mv;
+    float v1, v2, cr1, cr2;
+};
+
+AR_HD void backup_begin(BackupLane& b) {
+    b.state = B_ENTRY;
+    b.i = b.j = 0;
+    b.parent = b.po = b.mv = 0;
+    b.v1 = b.v2 = b.cr1 = b.cr2 = 0.0f;
+}
+
+// One round of the lane's current backup state. `ev` holds b_nn results in gather order.
 template <int NW>
-AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const EvalOut* ev, const ZigTables* zt) {
-    uint32_t state = B_ENTRY;
-    uint32_t i = 0, j = 0;  // proc index, eval index
-    uint32_t parent = 0, po = 0, mv = 0;
-    float v1 = 0.0f, v2 = 0.0f, cr1 = 0.0f, cr2 = 0.0f;
-    for (;;) {
-        const uint32_t run = elect_state(state, B_DONE, B_DONE);
-        if (run == B_DONE) break;
-        if (state != run) continue;
-        if (state == B_LEVEL) {
-            // search.rs:834-851 one ancestor: everything of the parent arrives in one round trip
-            NodeStats& P = m.stats[parent];
-            NodeH0 a = P.h0;
-            const NodeH1 b = P.h1;
-            const NodeH2 c = P.h2;
-            const uint32_t a1 = po & 0xffu, a2 = po >> 8;
-            Edge e1 = P.e[0][a1], e2 = P.e[1][a2];
-            const float q1 = cr1 + v1, q2 = cr2 + v2;
-            finalize_h0(a, q1, q2, 1);
-            edge_update(e1, q1, 1);
-            edge_update(e2, q2, 1);
-            P.h0 = a;
-            P.e[0][a1] = e1;
-            P.e[1][a2] = e2;
-            s.nv_backup += 1;
-            v1 = q1;
-            v2 = q2;
-            cr1 = b.r1;
-            cr2 = b.r2;
-            po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
-            parent = b.parent;
-            if (parent == NIL) state = B_ENTRY;
-        } else if (state == B_ENTRY) {
-            if (i >= s.n_proc) {
-                i = 0;
-                state = B_CANCEL;
-            } else {
-                const ProcEntry pe = m.proc[i++];
-                NodeStats& N = m.stats[pe.node];
-                NodeH0 a = N.h0;
-                const NodeH1 b = N.h1;
-                const NodeH2 c = N.h2;
-                float g1 = 0.0f, g2 = 0.0f;
-                if (pe.kind == PROC_EVAL) {
-                    const EvalOut o = ev[j++];
-                    float red1[5], red2[5];
-                    reduce_prior(c.omap[0], o.p1, red1);  // populate_node (tree.rs:156-173)
-                    reduce_prior(c.omap[1], o.p2, red2);
-                    if (pe.node == s.root && cfg.noise_epsilon > 0.0f) {  // search.rs:1036-1050
-                        const bool ok1 = dirichlet_mix(red1, meta_n(c.meta, 0), cfg.noise_epsilon, cfg.noise_concentration,
-                                                       s.rng, zt);
-                        const bool ok2 = dirichlet_mix(red2, meta_n(c.meta, 1), cfg.noise_epsilon, cfg.noise_concentration,
-                                                       s.rng, zt);
-                        if (!ok1 || !ok2) s.error = 5;
-                    }
-                    for (int k = 0; k < 5; ++k) {
-                        N.e[0][k].prior = red1[k];
-                        N.e[1][k].prior = red2[k];
-                    }
-                    g1 = o.v1;
-                    g2 = o.v2;
-                }
-                finalize_h0(a, g1, g2, 1);  // leaf: finalize_score_update
-                N.h0 = a;
-                s.nv_backup += 1;
-                v1 = g1;
-                v2 = g2;
-                cr1 = b.r1;
-                cr2 = b.r2;
-                po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
-                parent = b.parent;
-                if (parent != NIL) state = B_LEVEL;
-            }
-        } else if (state == B_CANCEL) {
-            // search.rs:860-889 cancel_shared_collisions
-            if (i >= s.n_coll) {
-                state = B_DONE;
-            } else {
-                const CollEntry ce = m.coll[i++];
-                mv = ce.mv;
-                const NodeH1 b = m.stats[ce.node].h1;
-                const NodeH2 c = m.stats[ce.node].h2;
-                po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
-                parent = b.parent;
-                if (parent != NIL) state = B_CANCEL_LEVEL;
-            }
-        } else {  // B_CANCEL_LEVEL
-            NodeStats& P = m.stats[parent];
-            const NodeH1 b = P.h1;
-            const NodeH2 c = P.h2;
-            const uint32_t a1 = po & 0xffu, a2 = po >> 8;
-            P.h0.nif -= mv;
-            P.e[0][a1].nif -= mv;
-            P.e[1][a2].nif -= mv;
-            po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
-            parent = b.parent;
-            if (parent == NIL) state = B_CANCEL;
+AR_HD void backup_round(BackupLane& b, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const EvalOut* ev,
+                        const ZigTables* zt) {
+    if (b.state == B_LEVEL) {
+        // search.rs:834-851 one ancestor: everything of the parent arrives in one round trip
+        NodeStats& P = m.stats[b.parent];
+        NodeH0 a = P.h0;
+        const NodeH1 h = P.h1;
+        const NodeH2 c = P.h2;
+        const uint32_t a1 = b.po & 0xffu, a2 = b.po >> 8;
+        Edge e1 = P.e[0][a1], e2 = P.e[1][a2];
+        const float q1 = b.cr1 + b.v1, q2 = b.cr2 + b.v2;
+        finalize_h0(a, q1, q2, 1);
+        edge_update(e1, q1, 1);
+        edge_update(e2, q2, 1);
+        P.h0 = a;
+        P.e[0][a1] = e1;
+        P.e[1][a2] = e2;
+        s.nv_backup += 1;
+        b.v1 = q1;
+        b.v2 = q2;
+        b.cr1 = h.r1;
+        b.cr2 = h.r2;
+        b.po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+        b.parent = h.parent;
+        if (b.parent == NIL) b.state = B_ENTRY;
+    } else if (b.state == B_ENTRY) {
+        if (b.i >= s.n_proc) {
+            b.i = 0;
+            b.state = B_CANCEL;
+            return;
         }
+        const ProcEntry pe = m.proc[b.i++];
+        NodeStats& N = m.stats[pe.node];
+        NodeH0 a = N.h0;
+        const NodeH1 h = N.h1;
+        const NodeH2 c = N.h2;
+        float g1 = 0.0f, g2 = 0.0f;
+        if (pe.kind == PROC_EVAL) {
+            const EvalOut o = ev[b.j++];
+            float red1[5], red2[5];
+            reduce_prior(c.omap[0], o.p1, red1);  // populate_node (tree.rs:156-173)
+            reduce_prior(c.omap[1], o.p2, red2);
+            if (pe.node == s.root && cfg.noise_epsilon > 0.0f) {  // search.rs:1036-1050
+                const bool ok1 =
+                    dirichlet_mix(red1, meta_n(c.meta, 0), cfg.noise_epsilon, cfg.noise_concentration, s.rng, zt);
+                const bool ok2 =
+                    dirichlet_mix(red2, meta_n(c.meta, 1), cfg.noise_epsilon, cfg.noise_concentration, s.rng, zt);
+                if (!ok1 || !ok2) s.error = 5;
+            }
+            for (int k = 0; k < 5; ++k) {
+                N.e[0][k].prior = red1[k];
+                N.e[1][k].prior = red2[k];
+            }
+            g1 = o.v1;
+            g2 = o.v2;
+        }
+        finalize_h0(a, g1, g2, 1);  // leaf: finalize_score_update
+        N.h0 = a;
+        s.nv_backup += 1;
+        b.v1 = g1;
+        b.v2 = g2;
+        b.cr1 = h.r1;
+        b.cr2 = h.r2;
+        b.po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+        b.parent = h.parent;
+        if (b.parent != NIL) b.state = B_LEVEL;
+    } else if (b.state == B_CANCEL) {
+        // search.rs:860-889 cancel_shared_collisions
+        if (b.i >= s.n_coll) {
+            b.state = B_DONE;
+            return;
+        }
+        const CollEntry ce = m.coll[b.i++];
+        b.mv = ce.mv;
+        const NodeH1 h = m.stats[ce.node].h1;
+        const NodeH2 c = m.stats[ce.node].h2;
+        b.po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+        b.parent = h.parent;
+        if (b.parent != NIL) b.state = B_CANCEL_LEVEL;
+    } else if (b.state == B_CANCEL_LEVEL) {
+        NodeStats& P = m.stats[b.parent];
+        const NodeH1 h = P.h1;
+        const NodeH2 c = P.h2;
+        const uint32_t a1 = b.po & 0xffu, a2 = b.po >> 8;
+        P.h0.nif -= b.mv;
+        P.e[0][a1].nif -= b.mv;
+        P.e[1][a2].nif -= b.mv;
+        b.po = meta_po(c.meta, 0) | (meta_po(c.meta, 1) << 8);
+        b.parent = h.parent;
+        if (b.parent == NIL) b.state = B_CANCEL;
     }
+}
+
+// search.rs:378-381 after the backup of one batch. Returns true when the search is complete.
+template <int NW>
+AR_HD bool batch_end(Slot<NW>& s) {
     s.s_nn += s.b_nn;
     s.s_term += s.b_term;
     s.s_coll += s.b_coll;
@@ -849,6 +899,63 @@ AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, c
     s.n_coll = 0;
     s.batch_active = 0;
     return s.remaining == 0;
+}
+
+// backup of one simulate_batch for every lane of the wavefront (split kernels)
+template <int NW>
+AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const EvalOut* ev, const ZigTables* zt) {
+    BackupLane b;
+    backup_begin(b);
+    for (;;) {
+        const uint32_t run = elect_state(b.state, B_DONE, B_DONE, 1);
+        if (run == B_DONE) break;
+        if (b.state == run) backup_round(b, s, m, cfg, ev, zt);
+    }
+    return batch_end(s);
+}
+
+template <int NW>
+AR_HD void finish_move(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg);
+
+// Fused form for evaluators computed inside the gather (SmartUniform): every lane runs up to `iters`
+// whole simulate_batch cycles (gather -> backup -> bookkeeping) back to back without waiting for
+// the other lanes between phases; the wavefront elects over the union of gather and backup states.
+// A lane leaves when it has done its batches, finished a search (tree reuse is a separate kernel),
+// or stalled for arena space.
+template <int NW>
+AR_HD void fused_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const ZigTables* zt, int iters) {
+    enum { OFF_B = 8, ST_DONE = 16 };
+    GatherLane<NW> g;
+    BackupLane b;
+    backup_begin(b);
+    int left_iters = iters;
+    uint32_t st = ST_DONE;  // combined state: gather states 0..3, backup states 8..11
+    if (s.status == SLOT_ACTIVE && left_iters > 0 && gather_begin(g, s, cfg, EVAL_UNIFORM)) st = g.state;
+    else g.state = G_DONE;
+    for (;;) {
+        const uint32_t run = elect_state(st, ST_DONE, ST_DONE, 0);
+        if (run == ST_DONE) break;
+        if (st != run) continue;
+        if (st < OFF_B) {
+            gather_round(g, s, m, cfg);
+            if (g.state == G_DONE) {
+                backup_begin(b);
+                st = OFF_B + b.state;
+            } else {
+                st = g.state;
+            }
+        } else {
+            backup_round(b, s, m, cfg, m.ev_local, zt);
+            if (b.state == B_DONE) {
+                st = ST_DONE;
+                left_iters -= 1;
+                if (batch_end(s)) finish_move(s, m, cfg);
+                if (s.status == SLOT_ACTIVE && left_iters > 0 && gather_begin(g, s, cfg, EVAL_UNIFORM)) st = g.state;
+            } else {
+                st = OFF_B + b.state;
+            }
+        }
+    }
 }
 
 // search.rs:899-910 + :945-955: revert a gathered batch after an evaluator failure

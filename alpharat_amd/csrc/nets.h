@@ -415,10 +415,13 @@ __global__ void k_encode(const ar::LeafReq<NW>* q, uint32_t n, const ar::Board* 
 
 }  // namespace arnet
 
+#include "nets_cnn.h"
+
 // ---- host object --------------------------------------------------------------------------------
 struct ArNet {
     int device = 0;
     arnet::NetDev dev;
+    arnet::CnnDev cnn;
     std::vector<void*> allocs;
     float* cmaze = nullptr;
     const uint8_t* bound_pool = nullptr;
@@ -506,8 +509,86 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         d.n_head = 6;
         d.Kh = 2 * d.H;
         net->smem = (size_t)5 * TILE_SYM * (d.H + 4) * 4;
+    } else if (b.arch == ARCH_CNN) {
+        CnnDev& c = net->cnn;
+        memset(&c, 0, sizeof c);
+        c.width = d.width;
+        c.height = d.height;
+        c.hw = d.hw;
+        if (d.width > 8 || d.height > 8) return nets_fail(AR_E_BACKEND, "the CNN kernel handles boards up to 8x8");
+        const std::vector<float>* sw = b.get("stem.weight");
+        if (!sw || b.dims.at("stem.weight").size() != 4) return nets_fail(AR_E_BACKEND, "weight blob lacks stem.weight");
+        c.C = (int)b.dims.at("stem.weight")[0];
+        if (b.dims.at("stem.weight")[1] != 5 || (c.C != 16 && c.C != 32 && c.C != 64))
+            return nets_fail(AR_E_BACKEND, "CNN trunk must have 5 input planes and 16, 32 or 64 channels");
+        std::vector<double> sa, sb;
+        if (!bn_affine(b, "stem_bn", c.C, sa, sb, err)) return nets_fail(AR_E_BACKEND, err);
+        c.stem_w = net->upload(conv_t(*sw, c.C, 5, &sa), ok);
+        c.stem_b = net->upload(std::vector<float>(sb.begin(), sb.end()), ok);
+        size_t small_floats = 0;
+        for (int bi = 0;; ++bi) {
+            const std::string p = "blocks." + std::to_string(bi);
+            const std::vector<float>*w1 = b.get(p + ".conv1.weight"), *w2 = b.get(p + ".conv2.weight");
+            if (!w1) break;
+            if (bi >= CNN_MAX_BLOCKS) return nets_fail(AR_E_BACKEND, "too many trunk blocks");
+            if (!w2) return nets_fail(AR_E_BACKEND, "weight blob lacks " + p + ".conv2.weight");
+            CnnBlockDev& k = c.blk[bi];
+            std::vector<double> a1, b1, a2, b2;
+            if (!bn_affine(b, p + ".bn1", c.C, a1, b1, err) || !bn_affine(b, p + ".bn2", c.C, a2, b2, err))
+                return nets_fail(AR_E_BACKEND, err);
+            k.bn1_a = net->upload(std::vector<float>(a1.begin(), a1.end()), ok);
+            k.bn1_b = net->upload(std::vector<float>(b1.begin(), b1.end()), ok);
+            k.w1 = net->upload(conv_t(*w1, c.C, c.C, &a2), ok);
+            k.b1 = net->upload(std::vector<float>(b2.begin(), b2.end()), ok);
+            k.w2 = net->upload(conv_t(*w2, c.C, c.C, nullptr), ok);
+            k.gpool = 0;
+            if (const std::vector<float>* pw = b.get(p + ".pool_conv.weight")) {
+                const int G = (int)b.dims.at(p + ".pool_conv.weight")[0];
+                k.gpool = G;
+                std::vector<double> pa, pb;
+                if (!bn_affine(b, p + ".pool_bn", c.C, pa, pb, err)) return nets_fail(AR_E_BACKEND, err);
+                k.pbn_a = net->upload(std::vector<float>(pa.begin(), pa.end()), ok);
+                k.pbn_b = net->upload(std::vector<float>(pb.begin(), pb.end()), ok);
+                std::vector<float> wpt((size_t)c.C * G);
+                for (int g = 0; g < G; ++g)
+                    for (int ci = 0; ci < c.C; ++ci) wpt[(size_t)ci * G + g] = (*pw)[(size_t)g * c.C + ci];
+                k.wp = net->upload(wpt, ok);
+                const std::vector<float>*lw = b.get(p + ".pool_linear.weight"), *lb = b.get(p + ".pool_linear.bias");
+                if (!lw || !lb) return nets_fail(AR_E_BACKEND, "weight blob lacks " + p + ".pool_linear");
+                std::vector<float> wlt((size_t)2 * G * c.C);
+                for (int o = 0; o < c.C; ++o)
+                    for (int kk = 0; kk < 2 * G; ++kk) wlt[(size_t)kk * c.C + o] = (*lw)[(size_t)o * 2 * G + kk];
+                k.wl = net->upload(wlt, ok);
+                k.bl = net->upload(*lb, ok);
+                if ((size_t)CNN_TILE * (c.C + 2 * G) > small_floats) small_floats = (size_t)CNN_TILE * (c.C + 2 * G);
+            }
+            c.n_blocks = bi + 1;
+        }
+        if (!fold_linear(b, "player_encoder.0", "", wt, bias, in, out, err) || in != 3) return nets_fail(AR_E_BACKEND, "bad player_encoder");
+        c.PD = (int)out;
+        c.pe_w = net->upload(wt, ok);
+        c.pe_b = net->upload(bias, ok);
+        if (!fold_linear(b, "combiner.0", "", wt, bias, in, out, err) || (int)in != c.C + c.PD) return nets_fail(AR_E_BACKEND, "bad combiner");
+        c.HD = (int)out;
+        c.cb_w = net->upload(wt, ok);
+        c.cb_b = net->upload(bias, ok);
+        const std::vector<float>*pw = b.get("policy_head.linear.weight"), *pb = b.get("policy_head.linear.bias"),
+                          *vw = b.get("value_head.linear.weight"), *vb = b.get("value_head.linear.bias");
+        if (!pw || !pb || !vw || !vb) return nets_fail(AR_E_BACKEND, "only the mlp policy head and the point value head are built");
+        std::vector<float> wh((size_t)6 * 2 * c.HD), bh(6);
+        memcpy(wh.data(), pw->data(), pw->size() * 4);
+        memcpy(&wh[(size_t)5 * 2 * c.HD], vw->data(), vw->size() * 4);
+        memcpy(bh.data(), pb->data(), 20);
+        bh[5] = (*vb)[0];
+        c.hd_w = net->upload(wh, ok);
+        c.hd_b = net->upload(bh, ok);
+        const size_t head_floats = (size_t)CNN_TILE * (2 * (c.C + c.PD) + 2 * c.HD + 12);
+        if (head_floats > small_floats) small_floats = head_floats;
+        const size_t chs = (size_t)(c.height + 2) * (c.width + 2);
+        net->smem = ((size_t)CNN_TILE * c.C * c.hw + 2 * (size_t)CNN_TILE * c.C * chs + small_floats + 64) * 4;
+        d.H = 4;  // unused by the CNN path
     } else {
-        return nets_fail(AR_E_BACKEND, "the CNN evaluator is not built in this revision (mlp and symmetric are)");
+        return nets_fail(AR_E_BACKEND, "unknown architecture id in the weight blob");
     }
     if (d.H % 4 != 0 || d.H > 1024) return nets_fail(AR_E_BACKEND, "hidden_dim must be a multiple of 4 and <= 1024");
     if (!ok) return nets_fail(AR_E_NOMEM, "device allocation failed while loading weights");
@@ -518,6 +599,11 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
 // per-maze first-layer constants for a pool of `n_mazes` cost tables of this net's board size
 static int net_bind_mazes(ArNet* net, const uint8_t* d_maze_pool, int n_mazes, hipStream_t stream) {
     if (net->bound_pool == d_maze_pool && net->bound_mazes == n_mazes) return AR_OK;
+    if (net->dev.arch == arnet::ARCH_CNN) {  // the CNN reads the maze planes itself
+        net->bound_pool = d_maze_pool;
+        net->bound_mazes = n_mazes;
+        return AR_OK;
+    }
     if (net->cmaze) hipFree(net->cmaze);
     net->cmaze = nullptr;
     if (hipMalloc((void**)&net->cmaze, (size_t)n_mazes * net->dev.H * 4) != hipSuccess)
@@ -537,9 +623,15 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
                       size_t board_stride, ar::EvalOut* out, float* logits, hipStream_t stream) {
     using namespace arnet;
     if (n_max == 0) return AR_OK;
-    const int tile = net->dev.arch == ARCH_MLP ? TILE_MLP : TILE_SYM;
+    const int tile = net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
-    if (net->dev.arch == ARCH_MLP) {
+    if (net->dev.arch == ARCH_CNN) {
+        if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_cnn<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         (int)net->smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
+        hipLaunchKernelGGL(k_cnn<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max, boards,
+                           board_stride, net->bound_pool, out, logits);
+    } else if (net->dev.arch == ARCH_MLP) {
         if (net->smem > 48 * 1024 &&
             hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) !=
                 hipSuccess)

@@ -1,0 +1,299 @@
+// PyRatCNN evaluator (alpharat/nn/models/cnn/model.py:123-230, cnn/blocks.py:10-79, cnn/heads.py:10-38)
+// in eval mode, fused with the encoder: trunk of pre-activation residual blocks (optionally with a
+// global-pooling branch), features gathered at the two player cells, DeepSet heads.
+//
+// One block of 256 threads evaluates a tile of CNN_TILE leaves with all activations in LDS:
+//   A  [leaf][C][hw]            trunk state x (residual stream)
+//   B,C[leaf][C][(h+2)(w+2)]    zero-bordered activations feeding the 3x3 convolutions
+// so a 3x3 tap never needs a bounds check. Thread t owns output channel t % C and the rows
+// y = t / C (mod 256/C): it keeps <= 2 rows x w columns x CNN_TILE accumulators in registers and, per
+// input channel, reads a (rows+2) x (w+2) patch from LDS (broadcast across the C threads that share
+// the rows) and one weight per tap from L2 (layout [ci][tap][co], coalesced over co).
+// BatchNorm that follows a convolution (stem_bn, bn2) is folded into it at load time; BatchNorm in
+// front of a ReLU on the residual stream (bn1, pool_bn) is a per-channel affine applied while the
+// padded copy is written. fp32 FMA throughout (f32 MFMA has the same peak on gfx950; moving these
+// loops onto v_mfma_f32_32x32x2_f32 is future work).
+#pragma once
+// (included from nets.h after the shared helpers)
+
+namespace arnet {
+
+static const int CNN_TILE = 2;
+static const int CNN_MAX_BLOCKS = 8;
+
+struct CnnBlockDev {
+    const float *bn1_a, *bn1_b;        // [C] affine of bn1
+    const float *w1, *b1;              // conv1 with bn2 folded: [C][9][C], [C]
+    const float* w2;                   // conv2 [C][9][C]
+    int gpool;                         // 0 = res, else gpool channels G
+    const float *pbn_a, *pbn_b;        // [C]
+    const float* wp;                   // pool_conv [C][G]  (ci-major)
+    const float *wl, *bl;              // pool_linear [2G][C], [C]
+};
+
+struct CnnDev {
+    int width, height, hw, C, PD, HD, n_blocks;
+    const float *stem_w, *stem_b;      // [5][9][C] (stem_bn folded), [C]
+    CnnBlockDev blk[CNN_MAX_BLOCKS];
+    const float *pe_w, *pe_b;          // player_encoder [3][PD], [PD]
+    const float *cb_w, *cb_b;          // combiner [(C+PD)][HD], [HD]
+    const float *hd_w, *hd_b;          // heads rows: policy 5, value 1 over 2*HD, row-major [6][2HD]
+    const uint8_t* maze;               // unused here (maze comes through the boards' maze_off)
+};
+
+// zero-bordered patch conv: out[l][co][y][x] = bias[co] + sum_ci sum_tap w[ci][tap][co] * in[l][ci][y+dy][x+dx]
+// `in` has stride WP = w+2 per row and (h+2)*WP per channel. Results handed to `emit(l, y, x, value)`.
+template <typename Emit>
+__device__ inline void conv3x3_tile(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
+                                    const float* in, int in_leaf_stride, int h, int w, int tid, Emit emit) {
+    const int co = tid % C, rg = tid / C, RG = NTHREADS / C;
+    const int WP = w + 2, chs = (h + 2) * WP;
+    if (rg >= h) return;
+    const int y0 = rg, y1 = rg + RG;  // RG >= 4 and h <= 8: at most two rows per thread
+    const bool two = y1 < h;
+    float acc[CNN_TILE][2][8];
+    const float bv = bias ? bias[co] : 0.0f;
+#pragma unroll
+    for (int l = 0; l < CNN_TILE; ++l)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) acc[l][r][x] = bv;
+    for (int ci = 0; ci < Cin; ++ci) {
+        float wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = wt[((size_t)ci * 9 + t) * C + co];
+#pragma unroll
+        for (int l = 0; l < CNN_TILE; ++l) {
+            const float* src = in + (size_t)l * in_leaf_stride + (size_t)ci * chs;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && !two) break;
+                const int y = r == 0 ? y0 : y1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float* row = src + (size_t)(y + dy) * WP;
+                    float v[10];
+#pragma unroll
+                    for (int x = 0; x < 10; ++x) v[x] = x < WP ? row[x] : 0.0f;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        acc[l][r][x] = fmaf(wv[dy * 3 + 2], v[x + 2], fmaf(wv[dy * 3 + 1], v[x + 1], fmaf(wv[dy * 3], v[x], acc[l][r][x])));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < CNN_TILE; ++l)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !two) break;
+            const int y = r == 0 ? y0 : y1;
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                if (x < w) emit(l, co, y, x, acc[l][r][x]);
+        }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                  uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                  const uint8_t* maze_pool, ar::EvalOut* out, float* logits) {
+    constexpr int L = CNN_TILE;
+    extern __shared__ float smem[];
+    const int C = net.C, h = net.height, w = net.width, hw = net.hw;
+    const int WP = w + 2, chs = (h + 2) * WP;
+    const int a_leaf = C * hw, p_leaf = C * chs;
+    float* A = smem;                          // [L][C][hw]
+    float* Bp = A + (size_t)L * a_leaf;       // [L][C][chs] padded
+    float* Cp = Bp + (size_t)L * p_leaf;      // [L][C][chs] padded
+    float* small = Cp + (size_t)L * p_leaf;   // [L][4*64] scratch for pooled / head vectors
+    __shared__ LeafFeat feat[L];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    // zero both padded buffers once: borders stay zero, interiors are always overwritten
+    for (int i = tid; i < 2 * L * p_leaf; i += NTHREADS) Bp[i] = 0.0f;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+    }
+    __syncthreads();
+    // spatial input (5 channels: maze up/right/down/left, cheese) into the padded buffer Cp[l][0..4]
+    for (int i = tid; i < L * 5 * hw; i += NTHREADS) {
+        const int l = i / (5 * hw), rem = i % (5 * hw), c = rem / hw, cell = rem % hw;
+        const int ll = l < cnt ? l : 0;
+        const ar::LeafReq<NW>& r = q[base + ll];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        float v;
+        if (c < 4) {
+            const uint8_t cst = maze_pool[b.maze_off + (uint32_t)cell * 4u + (uint32_t)c];
+            v = cst ? (float)cst / 10.0f : -1.0f;
+        } else {
+            v = ar::st_has_cheese(r.st, cell) ? 1.0f : 0.0f;
+        }
+        Cp[(size_t)l * p_leaf + (size_t)c * chs + (size_t)(cell / w + 1) * WP + (cell % w + 1)] = v;
+    }
+    __syncthreads();
+    // stem: conv(5 -> C) + folded stem_bn + ReLU -> A
+    conv3x3_tile(net.stem_w, net.stem_b, 5, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+        A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x] = fmaxf(v, 0.0f);
+    });
+    __syncthreads();
+    for (int bi = 0; bi < net.n_blocks; ++bi) {
+        const CnnBlockDev& blk = net.blk[bi];
+        float* pout = small;  // [L][C] pooled-branch output (gpool blocks)
+        if (blk.gpool) {
+            const int G = blk.gpool;
+            float* pc = Cp;  // reuse as [L][G][hw] (unpadded scratch); re-zeroed below
+            // pool path: relu(pool_bn(x)) -> 1x1 conv -> mean/max over cells
+            for (int i = tid; i < L * G * hw; i += NTHREADS) {
+                const int l = i / (G * hw), rem = i % (G * hw), g = rem / hw, cell = rem % hw;
+                float acc = 0.0f;
+                for (int c = 0; c < C; ++c) {
+                    const float xv = fmaxf(fmaf(blk.pbn_a[c], A[(size_t)l * a_leaf + (size_t)c * hw + cell], blk.pbn_b[c]), 0.0f);
+                    acc = fmaf(blk.wp[(size_t)c * G + g], xv, acc);
+                }
+                pc[(size_t)l * G * hw + (size_t)g * hw + cell] = acc;
+            }
+            __syncthreads();
+            float* pcat = small + L * C;  // [L][2G]
+            for (int i = tid; i < L * G; i += NTHREADS) {
+                const int l = i / G, g = i % G;
+                const float* p = pc + (size_t)l * G * hw + (size_t)g * hw;
+                float s = 0.0f, mx = p[0];
+                for (int c2 = 0; c2 < hw; ++c2) {
+                    s += p[c2];
+                    mx = fmaxf(mx, p[c2]);
+                }
+                pcat[l * 2 * G + g] = s / (float)hw;
+                pcat[l * 2 * G + G + g] = mx;
+            }
+            __syncthreads();
+            for (int i = tid; i < L * C; i += NTHREADS) {
+                const int l = i / C, c = i % C;
+                float acc = blk.bl[c];
+                for (int k = 0; k < 2 * G; ++k) acc = fmaf(blk.wl[(size_t)k * C + c], pcat[l * 2 * G + k], acc);
+                pout[l * C + c] = acc;
+            }
+            __syncthreads();
+            for (int i = tid; i < L * p_leaf; i += NTHREADS) Cp[i] = 0.0f;  // restore the zero borders
+            __syncthreads();
+        }
+        // Bp = pad(relu(bn1(A)))
+        for (int i = tid; i < L * a_leaf; i += NTHREADS) {
+            const int l = i / a_leaf, rem = i % a_leaf, c = rem / hw, cell = rem % hw;
+            Bp[(size_t)l * p_leaf + (size_t)c * chs + (size_t)(cell / w + 1) * WP + (cell % w + 1)] =
+                fmaxf(fmaf(blk.bn1_a[c], A[i], blk.bn1_b[c]), 0.0f);
+        }
+        __syncthreads();
+        // Cp = pad(relu(conv1'(Bp)))   (bn2 folded)
+        conv3x3_tile(blk.w1, blk.b1, C, C, Bp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+            Cp[(size_t)l * p_leaf + (size_t)co * chs + (size_t)(y + 1) * WP + (x + 1)] = fmaxf(v, 0.0f);
+        });
+        __syncthreads();
+        // A = conv2(Cp) [+ pooled] + A
+        conv3x3_tile(blk.w2, nullptr, C, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+            float* a = &A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x];
+            *a = blk.gpool ? v + pout[l * C + co] + *a : v + *a;
+        });
+        __syncthreads();
+    }
+    // heads: features at the player cells, player encoder, combiner, DeepSet heads
+    const int PD = net.PD, HD = net.HD;
+    float* cat = small;                    // [L][2][C+PD]
+    float* hid = cat + L * 2 * (C + PD);   // [L][2][HD]
+    float* hl = hid + L * 2 * HD;          // [L][12]
+    for (int i = tid; i < L * 2 * (C + PD); i += NTHREADS) {
+        const int l = i / (2 * (C + PD)), rem = i % (2 * (C + PD)), p = rem / (C + PD), k = rem % (C + PD);
+        const LeafFeat& f = feat[l];
+        float v;
+        if (k < C) {
+            v = A[(size_t)l * a_leaf + (size_t)k * hw + (p == 0 ? f.p1 : f.p2)];
+        } else {
+            const int o = k - C;
+            // side = [score, mud, progress]  (model.py:153-168)
+            const float s0 = f.sc[4 + p], s1 = f.sc[2 + p], s2 = f.sc[1];
+            float acc = net.pe_b[o];
+            acc = fmaf(net.pe_w[0 * PD + o], s0, acc);
+            acc = fmaf(net.pe_w[1 * PD + o], s1, acc);
+            acc = fmaf(net.pe_w[2 * PD + o], s2, acc);
+            v = fmaxf(acc, 0.0f);
+        }
+        cat[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 2 * HD; i += NTHREADS) {
+        const int l = i / (2 * HD), rem = i % (2 * HD), p = rem / HD, o = rem % HD;
+        const float* cv = cat + (size_t)(l * 2 + p) * (C + PD);
+        float acc = net.cb_b[o];
+        for (int k = 0; k < C + PD; ++k) acc = fmaf(net.cb_w[(size_t)k * HD + o], cv[k], acc);
+        hid[i] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 12; i += NTHREADS) {
+        const int l = i / 12, r = i % 12, p = r / 6, o = r % 6;
+        const float* hi = hid + (size_t)(l * 2 + p) * HD;
+        const float* h0 = hid + (size_t)(l * 2) * HD;
+        const float* h1 = h0 + HD;
+        const float* wr = net.hd_w + (size_t)o * 2 * HD;
+        float acc = net.hd_b[o];
+        for (int k = 0; k < HD; ++k) acc = fmaf(wr[k], hi[k], acc);
+        for (int k = 0; k < HD; ++k) acc = fmaf(wr[HD + k], h0[k] + h1[k], acc);
+        hl[i] = acc;
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 6, o.p2);
+        o.v1 = softplusf(hh[5]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 5; ++k) {
+                logits[(size_t)(base + tid) * 10 + k] = hh[k];
+                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
+            }
+    }
+}
+
+// ---- host: blob -> device weights ---------------------------------------------------------------
+struct CnnHost {
+    CnnDev dev;
+    size_t smem = 0;
+};
+
+// conv weight [co][ci][3][3] (optionally scaled per co) -> [ci][tap][co]
+inline std::vector<float> conv_t(const std::vector<float>& w, int co_n, int ci_n, const std::vector<double>* scale) {
+    std::vector<float> t((size_t)ci_n * 9 * co_n);
+    for (int co = 0; co < co_n; ++co)
+        for (int ci = 0; ci < ci_n; ++ci)
+            for (int k = 0; k < 9; ++k)
+                t[((size_t)ci * 9 + k) * co_n + co] =
+                    (float)((double)w[((size_t)co * ci_n + ci) * 9 + k] * (scale ? (*scale)[co] : 1.0));
+    return t;
+}
+inline bool bn_affine(const Blob& b, const std::string& p, int n, std::vector<double>& a, std::vector<double>& c,
+                      std::string& err) {
+    const std::vector<float>*g = b.get(p + ".weight"), *be = b.get(p + ".bias"), *m = b.get(p + ".running_mean"),
+                      *v = b.get(p + ".running_var");
+    if (!g || !be || !m || !v || (int)g->size() != n) {
+        err = "weight blob lacks " + p;
+        return false;
+    }
+    a.resize(n);
+    c.resize(n);
+    for (int i = 0; i < n; ++i) {
+        a[i] = (double)(*g)[i] / sqrt((double)(*v)[i] + 1e-5);
+        c[i] = (double)(*be)[i] - (double)(*m)[i] * a[i];
+    }
+    return true;
+}
+
+}  // namespace arnet

@@ -134,6 +134,10 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
             advance_tree_scalar(s, m);
             continue;
         }
+        if (eval_mode == 2) {  // the fused kernel body: several batches per call, SmartUniform inline
+            fused_machine(s, m, r->cfg, &g_zig, 3);
+            continue;
+        }
         if (!gather_machine(s, m, r->cfg, mode)) continue;
         const EvalOut* evp = m.ev_local;
         if (eval_mode != 0) {

@@ -45,12 +45,13 @@ def test_device_encoder_golden(path):
     np.testing.assert_allclose(got, np.asarray(fx["expected"], np.float32), atol=1e-6, rtol=0)
 
 
-@pytest.mark.parametrize("name", ["mlp_5x5_h32", "mlp_7x7_h256", "symmetric_5x5_h32", "symmetric_7x7_h256"])
+@pytest.mark.parametrize("name", ["mlp_5x5_h32", "mlp_7x7_h256", "symmetric_5x5_h32", "symmetric_7x7_h256",
+                                  "cnn_res_5x5_c16", "cnn_gpool_7x5_c16", "cnn_gpool_7x7_c64"])
 def test_device_net_matches_reference_outputs(name):
     from alpharat_amd.nets import Net, encode
 
     gold = np.load(GOLD / "nets" / f"{name}.npz")
-    w, h = (5, 5) if "5x5" in name else (7, 7)
+    w, h = (5, 5) if "5x5" in name else (7, 5) if "7x5" in name else (7, 7)
     games = [_game_from_obs(o, w, h) for o in gold["obs"]]
     np.testing.assert_allclose(encode(games), gold["obs"], atol=1e-6, rtol=0)
     out = Net(GOLD / "nets" / f"{name}.arnet").evaluate(games)
