@@ -546,139 +546,37 @@ AR_HD bool gather_begin(GatherLane<NW>& g, Slot<NW>& s, const SearchCfg& cfg, in
     return true;
 }
 
-// One round of the lane's current gather state.
+// One round of a lane's gather. Every lane that is not done runs the same sequence, so the wavefront
+// does not split by state:
+//   1. decide: pop a finished level (rare: only after a split allocation), start the next
+//      pick_nodes_to_extend call at the root, or take the next child slot of the current node
+//      (step the position, one load of the child id; a missing child is created and becomes a leaf
+//      right here, stores only);
+//   2. load the whole record of the node to look at -- the root or the existing child -- in one
+//      round trip and classify it: unvisited / terminal -> claim it as a batch entry (or collision);
+//      visited interior -> add the virtual loss, keep the level if siblings still wait, and expand
+//      it from the registers just loaded: scores, allocation loop, virtual-loss write-back.
+// So a descent costs one round (<= two dependent memory trips) per tree level.
 template <int NW>
 AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
-    if (g.state == G_CHILD) {
-        if (g.mask == 0) {
-            // level exhausted: backtrack (search.rs:728-734)
-            if (g.depth == 0) {
-                g.state = G_PICK;
-            } else {
-                g.depth -= 1;
-                const Level<NW>& L = m.levels[g.depth];
-                g.node = L.node;
-                g.mask = L.mask;
-                g.omap0 = L.omap[0];
-                g.omap1 = L.omap[1];
-                for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
-                g.work = L.saved;
-            }
-            return;
-        }
-        const uint32_t idx = (uint32_t)lowest_bit(g.mask);
-        g.mask &= g.mask - 1;
-        const uint32_t k = vtp_get(g.vtp, idx);
-        const uint32_t o1 = idx / 5, o2 = idx % 5;
-        const State<NW> before = g.work;
-        float r1, r2;
-        st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
-        uint32_t child = m.kids[g.node].c[idx];
-        bool leaf_path = true, ok = true;
-        uint32_t c_visits = 0, c_nif = 0, c_term = 0;
-        if (child == NIL) {
-            if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
-                s.error = 3;
-                ok = false;
-            } else {
-                child = s.hi++;
-                init_shell(m.stats[child], m.kids[child], eff_actions(m.cost, g.work.p1, g.work.m1),
-                           eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
-                m.kids[g.node].c[idx] = child;
-                s.node_count += 1;
-                s.new_nodes += 1;
-            }
-        } else {
-            const NodeH0 a = m.stats[child].h0;
-            c_visits = a.visits;
-            c_nif = a.nif;
-            c_term = m.stats[child].h2.terminal;
-            leaf_path = c_visits == 0 || c_term != 0;
-        }
-        if (!ok) {
-            g.work = before;
-        } else if (leaf_path) {
-            // search.rs:675-706
-            if (!(c_visits == 0 && c_nif > 0)) {  // try_start_score_update
-                m.stats[child].h0.nif = c_nif + 1;
-                if (c_term != 0 || st_over(s.board, g.work)) {
-                    if (c_visits == 0) m.stats[child].h2.terminal = 1;
-                    emit_proc(s, m, cfg, g.eval_mode, child, PROC_TERMINAL, g.work);
-                } else {
-                    emit_proc(s, m, cfg, g.eval_mode, child, PROC_EVAL, g.work);
-                }
-                if (k > 1) emit_coll(s, m, child, k - 1, g.pick_mv);
-            } else {
-                emit_coll(s, m, child, k, g.pick_mv);
-            }
-            g.work = before;
-        } else if (g.depth >= m.max_depth) {
-            s.error = 4;
-            g.work = before;
-        } else {
-            // search.rs:707-725: interior child, descend with k visits
-            m.stats[child].h0.nif = c_nif + k;
-            if (g.mask != 0) {  // children of this node still wait: keep the level for the way back
-                Level<NW>& L = m.levels[g.depth];
-                L.node = g.node;
-                L.mask = g.mask;
-                L.omap[0] = g.omap0;
-                L.omap[1] = g.omap1;
-                for (int j = 0; j < 13; ++j) L.vtp[j] = g.vtp[j];
-                L.saved = before;
-                g.depth += 1;
-            }
-            g.enter = child;
-            g.enter_budget = k;
-            g.enter_root = false;
-            g.state = G_ENTER;
-        }
-    } else if (g.state == G_ENTER) {
-        // load the node for expansion: everything select needs arrives in one round trip
-        const NodeStats& N = m.stats[g.enter];
-        Edge e1[5], e2[5];
-        for (int i = 0; i < 5; ++i) {
-            e1[i] = N.e[0][i];
-            e2[i] = N.e[1][i];
-        }
-        const NodeH0 a = N.h0;
-        const NodeH1 b = N.h1;
-        const NodeH2 c = N.h2;
-        const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
-        HalfAlloc h1, h2;
-        half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, g.enter_root);
-        half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, g.enter_root);
-        g.node = g.enter;
-        g.omap0 = c.omap[0];
-        g.omap1 = c.omap[1];
-        g.mask = 0;
-        for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
-        s.nv_gather += 1;
-        // search.rs:775-798: split the visits over child pairs (no memory traffic in this loop)
-        uint32_t remaining = g.enter_budget;
-        while (remaining > 0) {
-            uint32_t b1, b2, c1, c2;
-            half_best(h1, s.rng, b1, c1);
-            half_best(h2, s.rng, b2, c2);
-            uint32_t k = remaining;
-            if (c1 < k) k = c1;
-            if (c2 < k) k = c2;
-            if (k < 1) k = 1;
-            const uint32_t flat = b1 * 5 + b2;
-            vtp_add(g.vtp, flat, k);
-            g.mask |= 1u << flat;
-            half_take(h1, b1, k);
-            half_take(h2, b2, k);
-            remaining -= k;
-        }
-        // search.rs:800-814: write the virtual-loss deltas back
-        NodeStats& W = m.stats[g.node];
-        for (uint32_t i = 0; i < 5; ++i) {
-            if (h1.add[i]) W.e[0][i].nif = h1.nif0[i] + h1.add[i];
-            if (h2.add[i]) W.e[1][i].nif = h2.nif0[i] + h2.add[i];
-        }
-        g.state = G_CHILD;
-    } else if (g.state == G_PICK) {
+    if (g.state == G_DONE) return;
+    uint32_t rec = NIL;       // node whose record is inspected in step 2
+    uint32_t visits_in = 0;   // visits routed to it (pick budget or k)
+    bool from_pick = false;
+    State<NW> before = g.work;
+    if (g.mask == 0 && g.depth > 0) {
+        // level exhausted: backtrack (search.rs:728-734)
+        g.depth -= 1;
+        const Level<NW>& L = m.levels[g.depth];
+        g.node = L.node;
+        g.mask = L.mask;
+        g.omap0 = L.omap[0];
+        g.omap1 = L.omap[1];
+        for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
+        g.work = L.saved;
+        return;
+    }
+    if (g.mask == 0) {
         // search.rs:981-999 outer gather loop around pick_nodes_to_extend
         if (g.have_pick) {
             s.b_coll += g.pick_mv;
@@ -695,33 +593,117 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
         g.pick_mv = 0;
         g.have_pick = true;
         g.work = s.st;
-        g.depth = 0;
-        const uint32_t root = s.root;
-        const NodeH0 a = m.stats[root].h0;
-        const uint32_t term = m.stats[root].h2.terminal;
-        if (a.visits == 0 || term) {
-            // search.rs:591-636: unvisited or terminal root
-            const bool claim = !(a.visits == 0 && a.nif > 0);
-            if (claim) {
-                m.stats[root].h0.nif = a.nif + 1;
-                if (term || st_over(s.board, g.work)) {
-                    if (a.visits == 0) m.stats[root].h2.terminal = 1;
-                    emit_proc(s, m, cfg, g.eval_mode, root, PROC_TERMINAL, g.work);
-                } else {
-                    emit_proc(s, m, cfg, g.eval_mode, root, PROC_EVAL, g.work);
-                }
-                if (budget > 1) emit_coll(s, m, root, budget - 1, g.pick_mv);
+        before = g.work;
+        rec = s.root;
+        visits_in = budget;
+        from_pick = true;
+    } else {
+        const uint32_t idx = (uint32_t)lowest_bit(g.mask);
+        g.mask &= g.mask - 1;
+        const uint32_t k = vtp_get(g.vtp, idx);
+        const uint32_t o1 = idx / 5, o2 = idx % 5;
+        float r1, r2;
+        st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
+        const uint32_t child = m.kids[g.node].c[idx];
+        if (child == NIL) {
+            // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
+            if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
+                s.error = 3;
             } else {
-                emit_coll(s, m, root, budget, g.pick_mv);
+                const uint32_t nid = s.hi++;
+                init_shell(m.stats[nid], m.kids[nid], eff_actions(m.cost, g.work.p1, g.work.m1),
+                           eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
+                m.kids[g.node].c[idx] = nid;
+                s.node_count += 1;
+                s.new_nodes += 1;
+                m.stats[nid].h0.nif = 1;  // try_start_score_update on a fresh node
+                emit_proc(s, m, cfg, g.eval_mode, nid, st_over(s.board, g.work) ? PROC_TERMINAL : PROC_EVAL, g.work);
+                if (st_over(s.board, g.work)) m.stats[nid].h2.terminal = 1;
+                if (k > 1) emit_coll(s, m, nid, k - 1, g.pick_mv);
             }
-            // stay in G_PICK: the next round accounts for this pick
-        } else {
-            m.stats[root].h0.nif = a.nif + budget;  // search.rs:639
-            g.enter = root;
-            g.enter_budget = budget;
-            g.enter_root = true;
-            g.state = G_ENTER;
+            g.work = before;
+            return;
         }
+        rec = child;
+        visits_in = k;
+    }
+
+    // ---- step 2: the record of `rec`, one round trip ------------------------------------------
+    const NodeStats& N = m.stats[rec];
+    Edge e1[5], e2[5];
+    for (int i = 0; i < 5; ++i) {
+        e1[i] = N.e[0][i];
+        e2[i] = N.e[1][i];
+    }
+    const NodeH0 a = N.h0;
+    const NodeH1 b = N.h1;
+    const NodeH2 c = N.h2;
+    if (a.visits == 0 || c.terminal != 0) {
+        // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
+        if (!(a.visits == 0 && a.nif > 0)) {  // try_start_score_update
+            m.stats[rec].h0.nif = a.nif + 1;
+            if (c.terminal != 0 || st_over(s.board, g.work)) {
+                if (a.visits == 0) m.stats[rec].h2.terminal = 1;
+                emit_proc(s, m, cfg, g.eval_mode, rec, PROC_TERMINAL, g.work);
+            } else {
+                emit_proc(s, m, cfg, g.eval_mode, rec, PROC_EVAL, g.work);
+            }
+            if (visits_in > 1) emit_coll(s, m, rec, visits_in - 1, g.pick_mv);
+        } else {
+            emit_coll(s, m, rec, visits_in, g.pick_mv);
+        }
+        g.work = before;  // (a root pick leaves work == s.st; mask stays 0 -> next round picks again)
+        return;
+    }
+    if (!from_pick && g.depth >= m.max_depth) {
+        s.error = 4;
+        g.work = before;
+        return;
+    }
+    // visited interior node: route the visits through it (search.rs:639 / :707-725)
+    m.stats[rec].h0.nif = a.nif + visits_in;
+    if (!from_pick && g.mask != 0) {  // siblings still wait: keep the parent level for the way back
+        Level<NW>& L = m.levels[g.depth];
+        L.node = g.node;
+        L.mask = g.mask;
+        L.omap[0] = g.omap0;
+        L.omap[1] = g.omap1;
+        for (int j = 0; j < 13; ++j) L.vtp[j] = g.vtp[j];
+        L.saved = before;
+        g.depth += 1;
+    }
+    if (from_pick) g.depth = 0;
+    // expand `rec` (search.rs:742-817 build_gather_level) from the registers just loaded
+    const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
+    HalfAlloc h1, h2;
+    half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, from_pick);
+    half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, from_pick);
+    g.node = rec;
+    g.omap0 = c.omap[0];
+    g.omap1 = c.omap[1];
+    g.mask = 0;
+    for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
+    s.nv_gather += 1;
+    uint32_t remaining = visits_in;
+    while (remaining > 0) {  // search.rs:775-798, no memory traffic in this loop
+        uint32_t b1, b2, c1, c2;
+        half_best(h1, s.rng, b1, c1);
+        half_best(h2, s.rng, b2, c2);
+        uint32_t k = remaining;
+        if (c1 < k) k = c1;
+        if (c2 < k) k = c2;
+        if (k < 1) k = 1;
+        const uint32_t flat = b1 * 5 + b2;
+        vtp_add(g.vtp, flat, k);
+        g.mask |= 1u << flat;
+        half_take(h1, b1, k);
+        half_take(h2, b2, k);
+        remaining -= k;
+    }
+    NodeStats& W = m.stats[rec];  // search.rs:800-814: write the virtual-loss deltas back
+    for (uint32_t i = 0; i < 5; ++i) {
+        if (h1.add[i]) W.e[0][i].nif = h1.nif0[i] + h1.add[i];
+        if (h2.add[i]) W.e[1][i].nif = h2.nif0[i] + h2.add[i];
     }
 }
 
