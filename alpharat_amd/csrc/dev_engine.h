@@ -52,14 +52,17 @@ AR_HD bool st_over(const Board& b, const State<NW>& s) {
 }
 
 // effective action map packed 3 bits per action (action a -> bits [3a, 3a+3))
+// the four direction costs of a cell in one 32-bit load (the table is 4-byte aligned per cell)
+AR_HD uint32_t cell_costs(const uint8_t* cost, uint32_t cell) { return ((const uint32_t*)cost)[cell]; }
+
 AR_HD uint32_t eff_actions(const uint8_t* cost, uint8_t cell, uint8_t mud) {
     if (mud > 0) return 4u | (4u << 3) | (4u << 6) | (4u << 9) | (4u << 12);
-    const uint8_t* c = cost + (uint32_t)cell * 4u;
+    const uint32_t c = cell_costs(cost, cell);
     uint32_t e = 4u << 12;
-    e |= (c[0] ? 0u : 4u);
-    e |= (c[1] ? 1u : 4u) << 3;
-    e |= (c[2] ? 2u : 4u) << 6;
-    e |= (c[3] ? 3u : 4u) << 9;
+    e |= ((c & 0xffu) ? 0u : 4u);
+    e |= (((c >> 8) & 0xffu) ? 1u : 4u) << 3;
+    e |= (((c >> 16) & 0xffu) ? 2u : 4u) << 6;
+    e |= (((c >> 24) & 0xffu) ? 3u : 4u) << 9;
     return e;
 }
 
@@ -69,7 +72,7 @@ AR_HD void move_one(const uint8_t* cost, uint32_t width, uint8_t& cell, uint8_t&
         return;
     }
     if (dir >= 4u) return;
-    const uint8_t c = cost[(uint32_t)cell * 4u + dir];
+    const uint8_t c = (uint8_t)((cell_costs(cost, cell) >> (8u * dir)) & 0xffu);
     if (c == 0) return;
     const int delta = dir == DIR_UP ? (int)width : dir == DIR_RIGHT ? 1 : dir == DIR_DOWN ? -(int)width : -1;
     cell = (uint8_t)((int)cell + delta);

@@ -380,12 +380,16 @@ AR_HD void half_best(const HalfAlloc& h, Rng& rng, uint32_t& best_out, uint32_t&
 }
 
 AR_HD void half_take(HalfAlloc& h, uint32_t b, uint32_t k) {
-    for (uint32_t i = 0; i < 5; ++i)
-        if (i == b) {
-            h.ns[i] += k;
-            h.add[i] += k;
-            if (!((h.forced >> i) & 1u)) h.score[i] = h.util[i] + h.num[i] / (1.0f + (float)h.ns[i]);
-        }
+    // one division for the chosen outcome, then scatter with selects (no per-index divisions)
+    const uint32_t nsb = pick5u(h.ns, b) + k;
+    const float sc = pick5(h.util, b) + pick5(h.num, b) / (1.0f + (float)nsb);
+    const bool keep_forced = (h.forced >> b) & 1u;
+    for (uint32_t i = 0; i < 5; ++i) {
+        const bool hit = i == b;
+        h.ns[i] = hit ? nsb : h.ns[i];
+        h.add[i] += hit ? k : 0u;
+        h.score[i] = (hit && !keep_forced) ? sc : h.score[i];
+    }
 }
 
 AR_HD uint32_t vtp_get(const uint32_t* w, uint32_t idx) {
