@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
 // passes). Pass 1 decides keep/drop and new ids 64 nodes at a time (parents inside the same 64 are
 // resolved by lane shuffles, the running count by ballot + popcount); pass 2 moves kept nodes.
 template <int NW>
-__global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B) {
+__global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B, SearchCfg cfg) {
     const uint32_t slot = blockIdx.x;
     if (slot >= n_slots) return;
     if (slots[slot].status != SLOT_ADVANCE) return;
@@ -171,9 +171,30 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     Slot<NW> s = slots[slot];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
     const uint32_t keep_root = s.pending_root;
+    // a slot living in a grown arena goes back to its share of the pool as soon as the kept tree plus
+    // one search fits there again: the compaction then simply writes to the other arena
+    const bool grown = s.cap != B.cap0;
+    Slot<NW> home = s;
+    {
+        const long long base = (long long)slot * (long long)arena_bytes(B.cap0);
+        home.cap = B.cap0;
+        home.stats_off = base;
+        home.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
+        home.fwd_off = home.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
+    }
+    const Mem<NW> mh = resolve_mem<NW>(home, B.arena, B.scratch, slot, B.L, B.maze);
     if (keep_root == NIL) {
         if (lane == 0) {
-            make_root(s, m);
+            if (grown) {
+                s.cap = home.cap;
+                s.stats_off = home.stats_off;
+                s.kids_off = home.kids_off;
+                s.fwd_off = home.fwd_off;
+                s.release_grown = 1;
+                make_root(s, mh);
+            } else {
+                make_root(s, m);
+            }
             s.status = SLOT_ACTIVE;
             slots[slot] = s;
         }
@@ -216,6 +237,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     }
     __threadfence();  // all new ids are in L2 before any lane reads another lane's
     __syncthreads();
+    const bool go_home = grown && (cnt + cfg.n_sims + 2 * cfg.batch_size + 64 <= B.cap0);
     for (uint32_t base = first; base < hi; base += 64) {
         const uint32_t i = base + lane;
         uint32_t ni = NIL;
@@ -234,12 +256,24 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         }
         __syncthreads();  // every lane has read its node before any lane overwrites a source
         if (ni != NIL) {
-            m.stats[ni] = nd;
-            m.kids[ni] = kd;
+            if (go_home) {
+                mh.stats[ni] = nd;
+                mh.kids[ni] = kd;
+            } else {
+                m.stats[ni] = nd;
+                m.kids[ni] = kd;
+            }
         }
         __syncthreads();
     }
     if (lane == 0) {
+        if (go_home) {
+            s.cap = home.cap;
+            s.stats_off = home.stats_off;
+            s.kids_off = home.kids_off;
+            s.fwd_off = home.fwd_off;
+            s.release_grown = 1;
+        }
         s.root = 0;
         s.hi = cnt;
         s.node_count = cnt;
@@ -263,11 +297,12 @@ __global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots, Bases B) {
 // counts[0] done, [1] stalled, [2] active (incl. waiting for k_advance), [3] errors; lists hold slot ids
 template <int NW>
 __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts, uint32_t* done_list,
-                       uint32_t* stall_list) {
+                       uint32_t* stall_list, uint32_t* release_list) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     const uint32_t st = slots[i].status;
     if (slots[i].error) atomicAdd(&counts[3], 1u);
+    if (slots[i].release_grown) release_list[atomicAdd(&counts[4], 1u)] = i;
     if (st == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
     else if (st == SLOT_STALL) stall_list[atomicAdd(&counts[1], 1u)] = i;
     else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE) atomicAdd(&counts[2], 1u);
@@ -329,6 +364,11 @@ __global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, 
     o.stats_off = s.stats_off;
     o.kids_off = s.kids_off;
     out[i] = o;
+}
+template <int NW>
+__global__ void k_clear_release(Slot<NW>* slots, const uint32_t* list, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[list[i]].release_grown = 0;
 }
 template <int NW>
 __global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n) {
@@ -577,7 +617,7 @@ struct Engine {
     DevBuf<unsigned char> arena;
     DevBuf<uint8_t> maze;
     DevBuf<ZigTables> zig;
-    DevBuf<uint32_t> counts, done_list, stall_list;
+    DevBuf<uint32_t> counts, done_list, stall_list, release_list;
     DevBuf<StallInfo> stall_info;
     DevBuf<GameInit<NW>> init;
     DevBuf<DoneInfo<NW>> info;
@@ -586,7 +626,7 @@ struct Engine {
     DevBuf<LeafReq<NW>> queue;
     DevBuf<EvalOut> ev_queue;
     DevBuf<uint32_t> queue_count;
-    PinBuf<uint32_t> h_counts;
+    PinBuf<uint32_t> h_counts, h_release;
     PinBuf<StallInfo> h_stall;
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
@@ -639,7 +679,9 @@ struct Engine {
         HIP_TRY(zig.alloc(1));
         static const ZigTables host_zig = {AR_ZIG_NORM_X_INIT, AR_ZIG_NORM_F_INIT};
         HIP_TRY(hipMemcpyAsync(zig.p, &host_zig, sizeof host_zig, hipMemcpyHostToDevice, stream));
-        HIP_TRY(counts.alloc(4));
+        HIP_TRY(counts.alloc(8));
+        HIP_TRY(release_list.alloc(S));
+        HIP_TRY(h_release.alloc(S));
         HIP_TRY(done_list.alloc(S));
         HIP_TRY(stall_list.alloc(S));
         HIP_TRY(stall_info.alloc(S));
@@ -647,7 +689,7 @@ struct Engine {
         HIP_TRY(info.alloc(S));
         HIP_TRY(staging.alloc((size_t)S * max_turns));
         HIP_TRY(grow.alloc(S));
-        HIP_TRY(h_counts.alloc(4));
+        HIP_TRY(h_counts.alloc(8));
         HIP_TRY(h_stall.alloc(S));
         HIP_TRY(h_info.alloc(S));
         HIP_TRY(h_staging.alloc((size_t)S * max_turns));
@@ -694,7 +736,7 @@ struct Engine {
         hipLaunchKernelGGL(k_backup<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
                            from_queue ? ev_queue.p : (const EvalOut*)nullptr);
     }
-    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases()); }
+    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg); }
     void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
 
     // `n_launch` rounds of {`iters` simulate_batch per game, then tree reuse for the games that moved},
@@ -728,12 +770,22 @@ struct Engine {
 
     // after run_steps: status lists on the host. Also accumulates device time.
     int scan(uint32_t out_counts[4]) {
-        HIP_TRY(hipMemsetAsync(counts.p, 0, 16, stream));
+        HIP_TRY(hipMemsetAsync(counts.p, 0, 32, stream));
         hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
-                           stall_list.p);
+                           stall_list.p, release_list.p);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 32, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        if (const uint32_t n_rel = h_counts.p[4]) {  // slots that moved back to their pool share
+            HIP_TRY(hipMemcpyAsync(h_release.p, release_list.p, 4 * n_rel, hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_clear_release<NW>, dim3(grid(n_rel)), dim3(64), 0, stream, slots.p, release_list.p, n_rel);
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (uint32_t i = 0; i < n_rel; ++i) {
+                void*& p = slot_grown[h_release.p[i]];
+                if (p) hipFree(p);
+                p = nullptr;
+            }
+        }
         if (timed) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
@@ -1029,7 +1081,8 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
 
     Engine<NW> eng;
     eng.net = net;
-    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, 0, net != nullptr)) return rc;
+    const uint32_t arena_nodes = getenv("AR_ARENA_NODES") ? (uint32_t)atoi(getenv("AR_ARENA_NODES")) : 0u;  // test knob
+    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr)) return rc;
 
     BundleSink writer;
     const bool to_disk = p.output_dir != nullptr;

@@ -127,6 +127,8 @@ struct Slot {
     uint32_t cap, hi, root, node_count;
     uint32_t pending_root;  // SLOT_ADVANCE: child to keep (NIL = fresh root)
     uint32_t need_nodes;    // capacity a stalled slot asks for
+    uint32_t release_grown; // 1: the slot went back to its pool share; the host may free the grown arena
+    uint32_t pad1;
     // current search
     uint32_t remaining;
     uint32_t s_nn, s_term, s_coll;
@@ -342,23 +344,24 @@ AR_HD void half_best(const HalfAlloc& h, Rng& rng, uint32_t& best_out, uint32_t&
     const float NEG_INF = -__builtin_inff();
     uint32_t best = 0;
     float best_score = NEG_INF, best_util = NEG_INF, second = NEG_INF;
+#pragma unroll
     for (uint32_t i = 0; i < 5; ++i) {
-        if (i >= n) break;
-        const float sc = h.score[i];
-        if (sc > best_score) {
-            second = best_score;
-            best_score = sc;
-            best = i;
-            best_util = h.util[i];
-        } else if (sc > second) {
-            second = sc;
+        if (i < n) {
+            const float sc = h.score[i];
+            if (sc > best_score) {
+                second = best_score;
+                best_score = sc;
+                best = i;
+                best_util = h.util[i];
+            } else if (sc > second) {
+                second = sc;
+            }
         }
     }
     uint32_t ties = 1;
+#pragma unroll
     for (uint32_t i = 0; i < 5; ++i) {
-        if (i >= n) break;
-        if (i == best) continue;
-        if (fabsf(h.score[i] - best_score) < 1e-12f) {
+        if (i < n && i != best && fabsf(h.score[i] - best_score) < 1e-12f) {
             ties += 1;
             if (rng_below(rng, ties) == 0) {
                 best = i;
@@ -1015,30 +1018,35 @@ AR_HD void extract_player(const Edge* e, uint32_t n, uint32_t omap, float node_v
             }
         const float sqrt_total = sqrtf((float)(cv > 1 ? cv : 1));
         const float puct_star = best_qn + cfg.c_puct * best_prior * sqrt_total / (1.0f + best_v);
+#pragma unroll
         for (uint32_t i = 0; i < 5; ++i) {
-            if (i >= n) break;
-            if (i == best || qn[i] >= puct_star) {
-                pruned[i] = raw[i];
-            } else {
-                const float denom = puct_star - qn[i];
-                if (denom <= 0.0f) {
+            if (i < n) {
+                if (i == best || qn[i] >= puct_star) {
                     pruned[i] = raw[i];
                 } else {
-                    float nmin = cfg.c_puct * e[i].prior * sqrt_total / denom - 1.0f;
-                    if (!(nmin > 0.0f)) nmin = 0.0f;
-                    pruned[i] = raw[i] < nmin ? raw[i] : nmin;
+                    const float denom = puct_star - qn[i];
+                    if (denom <= 0.0f) {
+                        pruned[i] = raw[i];
+                    } else {
+                        float nmin = cfg.c_puct * e[i].prior * sqrt_total / denom - 1.0f;
+                        if (!(nmin > 0.0f)) nmin = 0.0f;
+                        pruned[i] = raw[i] < nmin ? raw[i] : nmin;
+                    }
                 }
             }
         }
     }
+#pragma unroll
     for (uint32_t i = 0; i < 5; ++i) {
-        if (i >= n) break;
-        const uint32_t act = outcome_action(omap, i);
-        for (uint32_t a = 0; a < 5; ++a)
-            if (a == act) {
-                visit_counts[a] = pruned[i];
-                prior5[a] = e[i].prior;
-            }
+        if (i < n) {
+            const uint32_t act = outcome_action(omap, i);
+#pragma unroll
+            for (uint32_t a = 0; a < 5; ++a)
+                if (a == act) {
+                    visit_counts[a] = pruned[i];
+                    prior5[a] = e[i].prior;
+                }
+        }
     }
     float sum = 0.0f;
     for (int i = 0; i < 5; ++i) sum += visit_counts[i];

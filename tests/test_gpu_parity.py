@@ -208,3 +208,20 @@ def test_invalid_arguments_raise():
     with pytest.raises(ValueError, match="device"):
         rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=1, simulations=10, output_dir=None,
                        device="tensorrt")
+
+
+def test_selfplay_bit_exact_under_arena_growth_and_shrink(monkeypatch):
+    """Tiny first arenas: trees outgrow them (stall -> doubled arena) and move back to the pool share
+    after the root advances; records must not change."""
+    from alpharat_amd.sampling import rust_self_play
+
+    monkeypatch.setenv("AR_ARENA_NODES", "256")
+    games = []
+    kw = dict(noise_epsilon=0.25, **TUNED)
+    stats = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=24, simulations=500,
+                           batch_size=16, output_dir=None, seed=0, concurrent_games=16, on_game=games.append, **kw)
+    assert stats.total_games == 24
+    cfg = O.make_config(**kw)
+    for g in games:
+        i = g["game_index"]
+        _check_game(g, O.play_game(O.Game(7, 7, 50).random_cheese(10, True, i), cfg, 500, 16, 0xA1FA0000 + i))
