@@ -117,6 +117,7 @@ EXPORTS = {
     "ar_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "ar_device_count": (C.c_int, []),
     "ar_device_sync": (C.c_int, [C.c_int]),
+    "ar_release_device_memory": (C.c_int, [C.c_int]),
     "ar_net_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "ar_net_free": (None, [C.c_void_p]),
     "ar_net_evaluate": (C.c_int, [C.c_void_p, C.POINTER(ArGameSpec), C.c_uint32] + [C.c_void_p] * 6),

@@ -69,6 +69,22 @@ struct DoneInfo {
     MoveResult last;
 };
 
+// Overflow blocks for trees that outgrow their first arena. Three size classes (2x, 4x, 8x the
+// first arena) carved once from the same allocation as the first arenas; free blocks sit on one
+// device-side stack per class. Kernels only POP from the free stacks and only APPEND to the return
+// lists, and k_pool_merge (launched between batches of tree kernels) moves returned blocks back to
+// the stacks -- so a block is never handed out while an earlier kernel may still read it, and no
+// stack sees a concurrent push and pop.
+enum { POOL_CLASSES = 3 };
+struct ArenaPool {
+    long long off[POOL_CLASSES];      // byte offset of the class region from the arena base
+    uint32_t n[POOL_CLASSES];         // blocks in the class
+    uint32_t* free_ids[POOL_CLASSES]; // [n] stack of free block indices
+    uint32_t* ret_ids[POOL_CLASSES];  // [n] blocks handed back since the last merge
+    int* top;                         // [POOL_CLASSES] entries on each free stack
+    uint32_t* ret_n;                  // [POOL_CLASSES]
+};
+
 // the three bases every tree kernel receives; all per-game addresses derive from them
 struct Bases {
     unsigned char* arena;    // pool of first arenas; grown arenas are addressed relative to it too
@@ -76,7 +92,68 @@ struct Bases {
     const uint8_t* maze;     // cost tables
     SlotLayout L;
     uint32_t cap0;           // nodes per first arena
+    ArenaPool pool;
 };
+
+__device__ inline uint32_t pool_cap(const Bases& B, int cls) { return B.cap0 << (cls + 1); }
+__device__ inline uint32_t pool_pop(const ArenaPool& P, int cls) {
+    if (P.n[cls] == 0) return NIL;
+    const int i = atomicSub(&P.top[cls], 1) - 1;
+    if (i < 0) {
+        atomicAdd(&P.top[cls], 1);
+        return NIL;
+    }
+    return __hip_atomic_load(&P.free_ids[cls][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void pool_give_back(const ArenaPool& P, uint32_t blk) {  // blk = Slot::pool_blk
+    const int cls = (int)(blk >> 24) - 1;
+    P.ret_ids[cls][atomicAdd(&P.ret_n[cls], 1u)] = blk & 0xFFFFFFu;
+}
+// smallest class holding `need` nodes, POOL_CLASSES if none does
+__device__ inline int pool_class_for(const Bases& B, uint32_t need) {
+    for (int c = 0; c < POOL_CLASSES; ++c)
+        if (pool_cap(B, c) >= need) return c;
+    return POOL_CLASSES;
+}
+// where a slot's arena fields point when it lives in its first arena / in pool block (cls, idx)
+template <int NW>
+__device__ inline void slot_at_home(Slot<NW>& s, const Bases& B, uint32_t slot) {
+    const long long base = (long long)slot * (long long)arena_bytes(B.cap0);
+    s.cap = B.cap0;
+    s.stats_off = base;
+    s.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
+    s.fwd_off = s.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
+    s.pool_blk = 0;
+}
+template <int NW>
+__device__ inline void slot_at_block(Slot<NW>& s, const Bases& B, int cls, uint32_t idx) {
+    const uint32_t cap = pool_cap(B, cls);
+    const long long base = B.pool.off[cls] + (long long)idx * (long long)arena_bytes(cap);
+    s.cap = cap;
+    s.stats_off = base;
+    s.kids_off = base + (long long)cap * (long long)sizeof(NodeStats);
+    s.fwd_off = s.kids_off + (long long)cap * (long long)sizeof(NodeKids);
+    s.pool_blk = ((uint32_t)(cls + 1) << 24) | idx;
+}
+// the arena a slot leaves behind: pool blocks go to the return list, host-grown ones are flagged
+template <int NW>
+__device__ inline void leave_arena(const Slot<NW>& old, Slot<NW>& s, const Bases& B) {
+    if (old.pool_blk) pool_give_back(B.pool, old.pool_blk);
+    else if (old.cap != B.cap0) s.release_grown = 1;
+}
+
+__global__ void k_pool_merge(ArenaPool P) {
+    const int c = blockIdx.x;
+    if (c >= POOL_CLASSES || P.n[c] == 0) return;
+    const uint32_t n = P.ret_n[c];
+    const int t = P.top[c];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) P.free_ids[c][t + (int)i] = P.ret_ids[c][i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        P.top[c] = t + (int)n;
+        P.ret_n[c] = 0;
+    }
+}
 
 template <int NW>
 __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, Bases B, SearchCfg cfg) {
@@ -84,13 +161,9 @@ __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t
     if (i >= n) return;
     const GameInit<NW> gi = init[i];
     Slot<NW> s = slots[gi.slot];
-    if (s.cap == 0 || gi.reset_arena) {  // first use of this slot (or after a release): its share of the pool
-        const long long base = (long long)gi.slot * (long long)arena_bytes(B.cap0);
-        s.cap = B.cap0;
-        s.stats_off = base;
-        s.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
-        s.fwd_off = s.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
-    }
+    // a new game starts in the slot's first arena (a host-grown arena was freed by the host already)
+    if (s.pool_blk) pool_give_back(B.pool, s.pool_blk);
+    slot_at_home(s, B, gi.slot);
     s.board = gi.board;
     s.st = gi.st;
     rng_seed(s.rng, gi.rng_seed);
@@ -158,45 +231,61 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
     slots[i] = s;
 }
 
-// Tree reuse (tree.rs:283-302): one wavefront per game re-roots the tree by the in-place sliding
-// compaction described in dev_search.h (advance_tree_scalar is the one-lane statement of the same
-// passes). Pass 1 decides keep/drop and new ids 64 nodes at a time (parents inside the same 64 are
-// resolved by lane shuffles, the running count by ballot + popcount); pass 2 moves kept nodes.
+// Tree reuse (tree.rs:283-302): one wavefront per game re-roots the tree by the sliding compaction
+// described in dev_search.h (advance_tree_scalar is the one-lane statement of the same passes).
+// Pass 1 decides keep/drop and new ids 64 nodes at a time (parents inside the same 64 are resolved
+// by lane shuffles, the running count by ballot + popcount); pass 2 moves kept nodes.
+// The compaction is also where a game changes arena: once the kept tree is counted, the slot picks
+// the smallest arena (its first arena or an overflow-pool class) that holds the kept tree plus one
+// full search, and pass 2 writes there. So a tree never runs out of room in the middle of a search,
+// and a tree that shrank gives its block back. A slot that stalled anyway (pool empty at the time)
+// is retried here on every launch: its nodes are copied unchanged into a bigger block.
 template <int NW>
 __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B, SearchCfg cfg) {
     const uint32_t slot = blockIdx.x;
     if (slot >= n_slots) return;
-    if (slots[slot].status != SLOT_ADVANCE) return;
+    const uint32_t status = slots[slot].status;
+    if (status != SLOT_ADVANCE && status != SLOT_STALL) return;
     const uint32_t lane = threadIdx.x;
     Slot<NW> s = slots[slot];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
-    const uint32_t keep_root = s.pending_root;
-    // a slot living in a grown arena goes back to its share of the pool as soon as the kept tree plus
-    // one search fits there again: the compaction then simply writes to the other arena
-    const bool grown = s.cap != B.cap0;
-    Slot<NW> home = s;
-    {
-        const long long base = (long long)slot * (long long)arena_bytes(B.cap0);
-        home.cap = B.cap0;
-        home.stats_off = base;
-        home.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
-        home.fwd_off = home.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
-    }
-    const Mem<NW> mh = resolve_mem<NW>(home, B.arena, B.scratch, slot, B.L, B.maze);
-    if (keep_root == NIL) {
+
+    if (status == SLOT_STALL) {
+        const int want = pool_class_for(B, s.need_nodes > s.cap + 1 ? s.need_nodes : s.cap + 1);
+        int cls = POOL_CLASSES;
+        uint32_t idx = NIL;
+        if (lane == 0)
+            for (cls = want; cls < POOL_CLASSES; ++cls)
+                if ((idx = pool_pop(B.pool, cls)) != NIL) break;
+        cls = __shfl(cls, 0, 64);
+        idx = (uint32_t)__shfl((int)idx, 0, 64);
+        if (idx == NIL) return;  // nothing free: the host sees the stall and decides
+        Slot<NW> d = s;
+        slot_at_block(d, B, cls, idx);
+        const Mem<NW> md = resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze);
+        const uint4* ss = (const uint4*)m.stats;
+        uint4* ds = (uint4*)md.stats;
+        for (uint32_t w = lane; w < s.hi * (uint32_t)(sizeof(NodeStats) / 16); w += 64) ds[w] = ss[w];
+        const uint4* sk = (const uint4*)m.kids;
+        uint4* dk = (uint4*)md.kids;
+        for (uint32_t w = lane; w < s.hi * (uint32_t)(sizeof(NodeKids) / 16); w += 64) dk[w] = sk[w];
         if (lane == 0) {
-            if (grown) {
-                s.cap = home.cap;
-                s.stats_off = home.stats_off;
-                s.kids_off = home.kids_off;
-                s.fwd_off = home.fwd_off;
-                s.release_grown = 1;
-                make_root(s, mh);
-            } else {
-                make_root(s, m);
-            }
-            s.status = SLOT_ACTIVE;
-            slots[slot] = s;
+            leave_arena(s, d, B);
+            d.status = SLOT_ACTIVE;
+            slots[slot] = d;
+        }
+        return;
+    }
+
+    const uint32_t keep_root = s.pending_root;
+    if (keep_root == NIL) {  // fresh root: back to the first arena
+        if (lane == 0) {
+            Slot<NW> d = s;
+            slot_at_home(d, B, slot);
+            leave_arena(s, d, B);
+            make_root(d, resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze));
+            d.status = SLOT_ACTIVE;
+            slots[slot] = d;
         }
         return;
     }
@@ -237,7 +326,35 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     }
     __threadfence();  // all new ids are in L2 before any lane reads another lane's
     __syncthreads();
-    const bool go_home = grown && (cnt + cfg.n_sims + 2 * cfg.batch_size + 64 <= B.cap0);
+
+    // destination arena: the smallest that holds the kept tree plus one search
+    const uint32_t need = cnt + cfg.n_sims + 2 * cfg.batch_size + 64;
+    const int cur = s.pool_blk ? (int)(s.pool_blk >> 24) - 1 : (s.cap == B.cap0 ? -1 : POOL_CLASSES /* host-grown */);
+    const int want = need <= B.cap0 ? -1 : pool_class_for(B, need);
+    Slot<NW> d = s;
+    bool moved = false;
+    if (want == -1) {
+        if (cur != -1) {
+            slot_at_home(d, B, slot);
+            moved = true;
+        }
+    } else if (want < POOL_CLASSES && want != cur) {
+        // growing: any class from `want` up; shrinking: only classes below the current one
+        const int last = (cur > want && cur < POOL_CLASSES) ? cur - 1 : POOL_CLASSES - 1;
+        int cls = POOL_CLASSES;
+        uint32_t idx = NIL;
+        if (lane == 0)
+            for (cls = want; cls <= last; ++cls)
+                if ((idx = pool_pop(B.pool, cls)) != NIL) break;
+        cls = __shfl(cls, 0, 64);
+        idx = (uint32_t)__shfl((int)idx, 0, 64);
+        if (idx != NIL) {
+            slot_at_block(d, B, cls, idx);
+            moved = true;
+        }
+    }
+    const Mem<NW> md = resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze);
+
     for (uint32_t base = first; base < hi; base += 64) {
         const uint32_t i = base + lane;
         uint32_t ni = NIL;
@@ -256,29 +373,18 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         }
         __syncthreads();  // every lane has read its node before any lane overwrites a source
         if (ni != NIL) {
-            if (go_home) {
-                mh.stats[ni] = nd;
-                mh.kids[ni] = kd;
-            } else {
-                m.stats[ni] = nd;
-                m.kids[ni] = kd;
-            }
+            md.stats[ni] = nd;
+            md.kids[ni] = kd;
         }
         __syncthreads();
     }
     if (lane == 0) {
-        if (go_home) {
-            s.cap = home.cap;
-            s.stats_off = home.stats_off;
-            s.kids_off = home.kids_off;
-            s.fwd_off = home.fwd_off;
-            s.release_grown = 1;
-        }
-        s.root = 0;
-        s.hi = cnt;
-        s.node_count = cnt;
-        s.status = SLOT_ACTIVE;
-        slots[slot] = s;
+        if (moved) leave_arena(s, d, B);
+        d.root = 0;
+        d.hi = cnt;
+        d.node_count = cnt;
+        d.status = SLOT_ACTIVE;
+        slots[slot] = d;
     }
 }
 
@@ -297,9 +403,11 @@ __global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots, Bases B) {
 // counts[0] done, [1] stalled, [2] active (incl. waiting for k_advance), [3] errors; lists hold slot ids
 template <int NW>
 __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts, uint32_t* done_list,
-                       uint32_t* stall_list, uint32_t* release_list) {
+                       uint32_t* stall_list, uint32_t* release_list, ArenaPool P) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
+    if (i == 0 && P.top)  // free overflow blocks per class, for the host's bookkeeping
+        for (int c = 0; c < POOL_CLASSES; ++c) counts[5 + c] = (uint32_t)(P.top[c] > 0 ? P.top[c] : 0);
     const uint32_t st = slots[i].status;
     if (slots[i].error) atomicAdd(&counts[3], 1u);
     if (slots[i].release_grown) release_list[atomicAdd(&counts[4], 1u)] = i;
@@ -371,10 +479,12 @@ __global__ void k_clear_release(Slot<NW>* slots, const uint32_t* list, uint32_t 
     if (i < n) slots[list[i]].release_grown = 0;
 }
 template <int NW>
-__global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n) {
+__global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n, Bases B) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Slot<NW>& s = slots[req[i].slot];
+    if (s.pool_blk) pool_give_back(B.pool, s.pool_blk);
+    s.pool_blk = 0;
     s.cap = req[i].cap;
     s.stats_off = req[i].stats_off;
     s.kids_off = req[i].kids_off;
@@ -604,6 +714,67 @@ struct PinBuf {
     }
 };
 
+// The arena allocation (first arenas + overflow pool) is by far the largest one, and the driver
+// clears device memory when it hands it out (~30 ms per GB measured, 6-7 s for a full MI355X). One
+// block per device is therefore kept between calls: a training loop that calls ar_selfplay_run once
+// per iteration pays for it once. ar_release_device_memory() (or AR_NO_ARENA_CACHE=1) gives it back.
+struct ArenaBlock {
+    unsigned char* p = nullptr;
+    size_t bytes = 0;
+};
+enum { MAX_DEVICES = 64 };
+static std::mutex g_arena_mu;
+static ArenaBlock g_arena_cache[MAX_DEVICES];
+
+static size_t arena_cached_bytes(int dev) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    return dev >= 0 && dev < MAX_DEVICES ? g_arena_cache[dev].bytes : 0;
+}
+static hipError_t arena_acquire(int dev, size_t bytes, ArenaBlock& out) {
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        if (dev >= 0 && dev < MAX_DEVICES) {
+            ArenaBlock& c = g_arena_cache[dev];
+            if (c.p && c.bytes >= bytes) {
+                out = c;
+                c = ArenaBlock();
+                return hipSuccess;
+            }
+            if (c.p) {  // too small for this call: make room for the new one
+                hipFree(c.p);
+                c = ArenaBlock();
+            }
+        }
+    }
+    out.bytes = bytes;
+    return hipMalloc((void**)&out.p, bytes);
+}
+static void arena_release(int dev, ArenaBlock b) {
+    if (!b.p) return;
+    if (!getenv("AR_NO_ARENA_CACHE") && dev >= 0 && dev < MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        ArenaBlock& c = g_arena_cache[dev];
+        if (!c.p) {
+            c = b;
+            return;
+        }
+        if (c.bytes < b.bytes) std::swap(c, b);  // keep the bigger of the two
+    }
+    hipFree(b.p);
+}
+struct ArenaHold {
+    unsigned char* p = nullptr;
+    ArenaBlock blk;
+    int dev = -1;
+    hipError_t alloc(int device, size_t bytes) {
+        dev = device;
+        const hipError_t e = arena_acquire(device, bytes, blk);
+        p = blk.p;
+        return e;
+    }
+    ~ArenaHold() { arena_release(dev, blk); }
+};
+
 template <int NW>
 struct Engine {
     int dev = 0;
@@ -614,7 +785,7 @@ struct Engine {
     uint32_t max_turns = 0, cap0 = 0;
     DevBuf<Slot<NW>> slots;
     DevBuf<unsigned char> scratch;
-    DevBuf<unsigned char> arena;
+    ArenaHold arena;
     DevBuf<uint8_t> maze;
     DevBuf<ZigTables> zig;
     DevBuf<uint32_t> counts, done_list, stall_list, release_list;
@@ -630,7 +801,11 @@ struct Engine {
     PinBuf<StallInfo> h_stall;
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
-    std::vector<void*> slot_grown;  // per slot: the arena allocated after a stall (nullptr = pool share)
+    std::vector<void*> slot_grown;  // per slot: the arena the host allocated after a stall (nullptr = none)
+    ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
+    uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
+    DevBuf<uint32_t> pool_ids;
+    DevBuf<int> pool_ctr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double device_ms = 0.0;
     uint64_t steps = 0;
@@ -654,11 +829,21 @@ struct Engine {
         b.maze = maze.p;
         b.L = L;
         b.cap0 = cap0;
+        b.pool = pool;
         return b;
     }
 
+    // bytes of device memory setup() takes besides the arenas, per resident game
+    static size_t per_game_overhead(const SearchCfg& c, uint32_t mt, bool need_queue) {
+        size_t b = make_layout<NW>(c, mt).total + sizeof(Slot<NW>) + sizeof(PosRec<NW>) * mt + sizeof(GameInit<NW>) +
+                   sizeof(DoneInfo<NW>) + sizeof(StallInfo) + sizeof(GrowReq) + 16;
+        if (need_queue) b += (size_t)c.batch_size * (sizeof(LeafReq<NW>) + sizeof(EvalOut));
+        return b;
+    }
+
+    // `pool_bytes`: device memory to carve into overflow blocks (0 = none: every growth goes through the host)
     int setup(int device, uint32_t n_slots, const SearchCfg& c, uint32_t mt, const std::vector<uint8_t>& maze_bytes,
-              uint32_t arena_nodes, bool need_queue) {
+              uint32_t arena_nodes, bool need_queue, size_t pool_bytes = 0) {
         dev = device;
         S = n_slots;
         cfg = c;
@@ -673,7 +858,42 @@ struct Engine {
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
-        HIP_TRY(arena.alloc((size_t)S * arena_bytes(cap0) + 256));
+        // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
+        size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
+        {
+            const double share[POOL_CLASSES] = {0.55, 0.33, 0.12};
+            uint32_t total_ids = 0;
+            for (int k = 0; k < POOL_CLASSES; ++k) {
+                const size_t blk = arena_bytes(cap0 << (k + 1));
+                size_t n = (size_t)((double)pool_bytes * share[k]) / blk;
+                if (n > S) n = S;
+                if (n >= (1u << 24)) n = (1u << 24) - 1;
+                pool.n[k] = (uint32_t)n;
+                pool.off[k] = (long long)pool_end;
+                pool_end = align_up(pool_end + n * blk, 256);
+                total_ids += (uint32_t)n;
+            }
+            if (total_ids > 0) {
+                HIP_TRY(pool_ids.alloc((size_t)total_ids * 2));
+                HIP_TRY(pool_ctr.alloc(2 * POOL_CLASSES));
+                std::vector<uint32_t> ids((size_t)total_ids * 2, 0u);
+                int ctr[2 * POOL_CLASSES];
+                uint32_t at = 0;
+                for (int k = 0; k < POOL_CLASSES; ++k) {
+                    pool.free_ids[k] = pool_ids.p + at;
+                    pool.ret_ids[k] = pool_ids.p + at + pool.n[k];
+                    for (uint32_t i = 0; i < pool.n[k]; ++i) ids[at + i] = i;
+                    at += 2 * pool.n[k];
+                    ctr[k] = (int)pool.n[k];
+                    ctr[POOL_CLASSES + k] = 0;
+                }
+                pool.top = pool_ctr.p;
+                pool.ret_n = (uint32_t*)(pool_ctr.p + POOL_CLASSES);
+                HIP_TRY(hipMemcpy(pool_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(pool_ctr.p, ctr, sizeof ctr, hipMemcpyHostToDevice));
+            }
+        }
+        HIP_TRY(arena.alloc(dev, pool_end + 256));
         HIP_TRY(maze.alloc(maze_bytes.size()));
         HIP_TRY(hipMemcpyAsync(maze.p, maze_bytes.data(), maze_bytes.size(), hipMemcpyHostToDevice, stream));
         HIP_TRY(zig.alloc(1));
@@ -711,7 +931,7 @@ struct Engine {
 
     int start_games(std::vector<GameInit<NW>>& games) {
         if (games.empty()) return AR_OK;
-        for (GameInit<NW>& g : games) {  // a new game starts from the slot's pool share again
+        for (GameInit<NW>& g : games) {  // a new game starts in the slot's first arena again
             g.reset_arena = 0;
             if (slot_grown[g.slot]) {
                 hipFree(slot_grown[g.slot]);  // the slot was drained: no kernel touches that arena any more
@@ -770,9 +990,10 @@ struct Engine {
 
     // after run_steps: status lists on the host. Also accumulates device time.
     int scan(uint32_t out_counts[4]) {
+        if (pool.top) hipLaunchKernelGGL(k_pool_merge, dim3(POOL_CLASSES), dim3(256), 0, stream, pool);
         HIP_TRY(hipMemsetAsync(counts.p, 0, 32, stream));
         hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
-                           stall_list.p, release_list.p);
+                           stall_list.p, release_list.p, pool);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 32, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -792,11 +1013,15 @@ struct Engine {
             timed = false;
         }
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
+        for (int c = 0; c < POOL_CLASSES; ++c)
+            if (pool.n[c] && h_counts.p[5 + c] < pool_low[c]) pool_low[c] = h_counts.p[5 + c];
         return AR_OK;
     }
 
     // stalled games get a doubled arena: live nodes are copied across unchanged (ids are arena-relative)
-    int handle_stalls(uint32_t n_stall) {
+    // `may_wait`: other games are still running, so a stalled game that cannot be given memory now
+    // simply stays stalled (k_advance retries it from the overflow pool on every launch)
+    int handle_stalls(uint32_t n_stall, bool may_wait = false) {
         if (n_stall == 0) return AR_OK;
         hipLaunchKernelGGL(k_read_stall<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, stall_list.p, n_stall,
                            stall_info.p);
@@ -810,9 +1035,20 @@ struct Engine {
             uint32_t ncap = si.cap * 2;
             while (ncap < si.need) ncap *= 2;
             unsigned char* na = nullptr;
-            if (hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess)
+            // keep a reserve: the runtime allocates kernel scratch and queues from the same memory
+            size_t free_b = 0, total_b = 0;
+            const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                              free_b > arena_bytes(ncap) + ((size_t)3 << 30);
+            if (!room || hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess) {
+                (void)hipGetLastError();
+                if (may_wait) {
+                    n_stall = i;  // the rest waits for blocks to come back
+                    reqs.resize(i);
+                    break;
+                }
                 return fail(AR_E_NOMEM, "out of device memory while growing a tree arena to " + std::to_string(ncap) +
                                             " nodes");
+            }
             if (slot_grown[si.slot]) old_arenas.push_back(slot_grown[si.slot]);
             slot_grown[si.slot] = na;
             GrowReq r;
@@ -827,8 +1063,9 @@ struct Engine {
                                    (size_t)si.hi * sizeof(NodeKids), hipMemcpyDeviceToDevice, stream));
             reqs[i] = r;
         }
+        if (n_stall == 0) return AR_OK;
         HIP_TRY(hipMemcpyAsync(grow.p, reqs.data(), sizeof(GrowReq) * n_stall, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_apply_grow<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall);
+        hipLaunchKernelGGL(k_apply_grow<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall, bases());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         for (void* p : old_arenas) hipFree(p);
@@ -1064,6 +1301,8 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     // resident games: bounded by the request, the caller's hint and the arena footprint
     uint32_t S = p.concurrent_games ? p.concurrent_games : 16384;
     if (S > p.num_games) S = p.num_games;
+    size_t pool_bytes = 0;
+    const uint32_t arena_nodes = getenv("AR_ARENA_NODES") ? (uint32_t)atoi(getenv("AR_ARENA_NODES")) : 0u;  // test knob
     if (S == 0) {
         memset(out, 0, sizeof *out);
         return AR_OK;
@@ -1072,17 +1311,31 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
         size_t free_b = 0, total_b = 0;
         if (hipSetDevice(device) != hipSuccess) return fail(AR_E_DEVICE, "hipSetDevice failed");
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const size_t per_game = (size_t)initial_arena_nodes(cfg) * (sizeof(NodeStats) + sizeof(NodeKids)) +
-                                make_layout<NW>(cfg, p.max_turns).total + sizeof(PosRec<NW>) * p.max_turns * 2 + 4096;
-        const size_t budget = free_b / 10 * 6;  // leave room for arenas that grow
+        free_b += arena_cached_bytes(device);  // the block kept from the previous call is ours to reuse
+        const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
+                                Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr);
+        const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
         if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
         if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
+        // the overflow pool gets what is left, minus a reserve for the evaluator's buffers and the
+        // (rare) arenas beyond the largest pool class, which the host allocates one by one
+        const size_t reserve = (size_t)4 << 30;
+        const size_t used = (size_t)S * per_game;
+        pool_bytes = free_b > used + reserve ? (free_b - used - reserve) / 100 * 85 : 0;
     }
+
+    // AR_TIMING=1 prints where the host wall time of this call went (stderr)
+    const bool timing = getenv("AR_TIMING") != nullptr;
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(now() - a).count(); };
+    auto tp = now();
 
     Engine<NW> eng;
     eng.net = net;
-    const uint32_t arena_nodes = getenv("AR_ARENA_NODES") ? (uint32_t)atoi(getenv("AR_ARENA_NODES")) : 0u;  // test knob
-    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr)) return rc;
+    if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
+    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr, pool_bytes)) return rc;
+    tm[0] = since(tp);
 
     BundleSink writer;
     const bool to_disk = p.output_dir != nullptr;
@@ -1122,12 +1375,14 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     };
 
     {
+        tp = now();
         std::vector<uint32_t> all(S);
         for (uint32_t i = 0; i < S; ++i) all[i] = i;
         if (int rc = refill(all)) {
             writer.finish();
             return rc;
         }
+        tm[1] = since(tp);
     }
 
     int rc = AR_OK;
@@ -1135,17 +1390,26 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     // latency on refills and arena growth costs little
     const int iters = 4, launches = 8;
     while (finished < p.num_games) {
+        tp = now();
         if ((rc = eng.run_steps(launches, iters)) != AR_OK) break;
+        tm[2] += since(tp);
+        tp = now();
         uint32_t c[4];
         if ((rc = eng.scan(c)) != AR_OK) break;
+        tm[3] += since(tp);
+        tp = now();
         if (c[3] != 0) {
             rc = fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel (slot.error != 0)");
             break;
         }
-        if (c[1] && (rc = eng.handle_stalls(c[1])) != AR_OK) break;
+        if (c[1] && (rc = eng.handle_stalls(c[1], c[2] > 0)) != AR_OK) break;
+        tm[4] += since(tp);
+        tp = now();
         if (c[0]) {
             const uint32_t n_done = c[0];
             if ((rc = eng.drain(n_done)) != AR_OK) break;
+            tm[5] += since(tp);
+            tp = now();
             std::vector<uint32_t> free_slots;
             for (uint32_t d = 0; d < n_done; ++d) {
                 const DoneInfo<NW>& di = eng.h_info.p[d];
@@ -1182,7 +1446,10 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
                 free_slots.push_back(di.slot);
                 ++finished;
             }
+            tm[6] += since(tp);
+            tp = now();
             if ((rc = refill(free_slots)) != AR_OK) break;
+            tm[7] += since(tp);
         }
         if (c[0] == 0 && c[1] == 0 && c[2] == 0 && finished < p.num_games && next_game >= p.num_games) {
             rc = fail(AR_E_DEVICE, "self-play stalled: no active games left but not all games finished");
@@ -1197,6 +1464,15 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     if (st.total_games == 0) st.min_turns = 0;
     st.device_secs = eng.device_ms / 1000.0;
     st.steps = eng.steps;
+    if (timing)
+        fprintf(stderr,
+                "[ar timing] games=%u resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "
+                "scan-wait %.3f grow %.3f (%llu) drain %.3f records %.3f refill %.3f | pool blocks %u/%u/%u, fewest free "
+                "%u/%u/%u\n",
+                p.num_games, S, st.elapsed_secs, st.device_secs, tm[0], tm[1], tm[2], tm[3], tm[4],
+                (unsigned long long)eng.grows, tm[5], tm[6], tm[7], eng.pool.n[0], eng.pool.n[1], eng.pool.n[2],
+                eng.pool.n[0] ? eng.pool_low[0] : 0u, eng.pool.n[1] ? eng.pool_low[1] : 0u,
+                eng.pool.n[2] ? eng.pool_low[2] : 0u);
     *out = st;
     return rc;
 }
@@ -1399,6 +1675,19 @@ int ar_debug_round_stats(unsigned long long* out32) {
     return AR_OK;
 }
 #endif
+
+int ar_release_device_memory(int device) {
+    int dev = 0;
+    if (int rc = parse_device("hip", device, dev)) return rc;
+    HIP_TRY(hipSetDevice(dev));
+    ArenaBlock b;
+    {
+        std::lock_guard<std::mutex> lk(g_arena_mu);
+        if (dev < MAX_DEVICES) std::swap(b, g_arena_cache[dev]);
+    }
+    if (b.p) HIP_TRY(hipFree(b.p));
+    return AR_OK;
+}
 
 int ar_device_sync(int device) {
     int dev = 0;

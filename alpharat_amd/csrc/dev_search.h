@@ -128,7 +128,7 @@ struct Slot {
     uint32_t pending_root;  // SLOT_ADVANCE: child to keep (NIL = fresh root)
     uint32_t need_nodes;    // capacity a stalled slot asks for
     uint32_t release_grown; // 1: the slot went back to its pool share; the host may free the grown arena
-    uint32_t pad1;
+    uint32_t pool_blk;      // 0: first arena or host-grown; else ((class + 1) << 24) | block index in the overflow pool
     // current search
     uint32_t remaining;
     uint32_t s_nn, s_term, s_coll;

@@ -189,6 +189,12 @@ def rust_self_play(*, width: int, height: int, cheese_count: int, max_turns: int
     return SelfPlayStats(out)
 
 
+def release_device_memory(device_index: int = 0) -> None:
+    """Frees the tree-arena allocation the library keeps on the device between rust_self_play calls
+    (include/alpharat_hip.h: ar_release_device_memory), e.g. before a training step that needs the HBM."""
+    _lib.check(_lib.load().ar_release_device_memory(int(device_index)))
+
+
 def preload_cuda_libs() -> None:
     """No-op: the reference calls this before non-CPU runs (rust_sampling.py:176-183)."""
 

@@ -88,7 +88,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=16384, help="games per GPU per step (all resident at once)")
+    ap.add_argument("--games", type=int, default=65536, help="games per GPU per step (all resident at once)")
     ap.add_argument("--evaluator", choices=["mlp", "uniform"], default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -91,6 +91,11 @@ size_t ar_last_error(char* buf, size_t cap);
 int ar_device_count(void);
 /* hipDeviceSynchronize on `device` (benchmark bracketing) */
 int ar_device_sync(int device);
+/* The library keeps one tree-arena allocation per device between calls (the driver clears device
+ * memory on allocation, seconds for a full MI355X; the reference's sampler likewise keeps its
+ * thread pool and backend alive across play_games calls, selfplay.rs:600-660). This frees it, e.g.
+ * before a training step that needs the HBM. AR_NO_ARENA_CACHE=1 in the environment disables the cache. */
+int ar_release_device_memory(int device);
 
 /* ---- evaluator: replaces OnnxBackend / TensorrtBackend (+ FlatEncoder) -----------------------
  * crates/alpharat-sampling/src/backends/onnx.rs:176-246, tensorrt.rs:423 ff., trt_shim.cpp:53-324.

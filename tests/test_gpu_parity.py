@@ -210,12 +210,16 @@ def test_invalid_arguments_raise():
                        device="tensorrt")
 
 
-def test_selfplay_bit_exact_under_arena_growth_and_shrink(monkeypatch):
-    """Tiny first arenas: trees outgrow them (stall -> doubled arena) and move back to the pool share
-    after the root advances; records must not change."""
+@pytest.mark.parametrize("pool", [True, False], ids=["overflow-pool", "host-grown"])
+def test_selfplay_bit_exact_under_arena_growth_and_shrink(monkeypatch, pool):
+    """Tiny first arenas: trees outgrow them in the middle of the first search (stall -> copied to a
+    bigger block), change arena at every root advance (overflow-pool classes, or arenas the host
+    allocates when the pool is off / too small), and move back when they shrink; records must not change."""
     from alpharat_amd.sampling import rust_self_play
 
     monkeypatch.setenv("AR_ARENA_NODES", "256")
+    if not pool:
+        monkeypatch.setenv("AR_NO_POOL", "1")
     games = []
     kw = dict(noise_epsilon=0.25, **TUNED)
     stats = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=24, simulations=500,
@@ -225,3 +229,28 @@ def test_selfplay_bit_exact_under_arena_growth_and_shrink(monkeypatch):
     for g in games:
         i = g["game_index"]
         _check_game(g, O.play_game(O.Game(7, 7, 50).random_cheese(10, True, i), cfg, 500, 16, 0xA1FA0000 + i))
+
+
+def test_arena_block_is_reused_and_released_between_calls():
+    """The arena allocation is kept between calls (dirty memory from the previous run) and can be
+    released: results are the same either way."""
+    from alpharat_amd.sampling import release_device_memory, rust_self_play
+
+    def run():
+        games = []
+        rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=12, simulations=64, batch_size=8,
+                       output_dir=None, seed=3, concurrent_games=8, on_game=games.append, **TUNED)
+        return {g["game_index"]: g for g in games}
+
+    a = run()
+    b = run()  # reuses the cached block
+    release_device_memory(0)
+    c = run()  # fresh allocation
+    release_device_memory(0)
+    release_device_memory(0)  # nothing cached: still fine
+    for i in a:
+        for other in (b, c):
+            assert a[i]["final_p1_score"] == other[i]["final_p1_score"]
+            np.testing.assert_array_equal(a[i]["policy_p1"], other[i]["policy_p1"])
+            np.testing.assert_array_equal(a[i]["visit_counts_p2"], other[i]["visit_counts_p2"])
+            np.testing.assert_array_equal(a[i]["value_p1"], other[i]["value_p1"])
