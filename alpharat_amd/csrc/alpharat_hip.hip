@@ -198,13 +198,19 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
 // Split form for evaluators that run outside the tree walk (networks, host callbacks).
 template <int NW>
 __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
-                                               LeafReq<NW>* queue, uint32_t* queue_count) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                               LeafReq<NW>* queue, uint32_t* queue_count, uint32_t max_rounds,
+                                               uint32_t lanes) {
+    // `lanes` games per wavefront (<= 64): fewer games per wave means more waves per SIMD to hide the
+    // dependent loads behind and fewer divergent paths per instruction stream
+    if (threadIdx.x >= lanes) return;
+    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE) return;
     Slot<NW> s = slots[i];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
-    if (gather_machine(s, m, cfg, EVAL_STORE) && queue != nullptr && s.b_nn > 0) {
+    // a batch that was already gathered and still waits for its backup is left alone
+    const int got = s.batch_active ? GATHER_PENDING : gather_machine_limited(s, m, cfg, EVAL_STORE, max_rounds);
+    if (got == GATHER_COMPLETE && queue != nullptr && s.b_nn > 0) {
         const uint32_t base = atomicAdd(queue_count, s.b_nn);
         s.eval_base = base;
         for (uint32_t j = 0; j < s.b_nn; ++j) {
@@ -220,8 +226,9 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
 
 template <int NW>
 __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
-                                               const ZigTables* zt, const EvalOut* ev_queue) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                               const ZigTables* zt, const EvalOut* ev_queue, uint32_t lanes) {
+    if (threadIdx.x >= lanes) return;
+    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE || !slots[i].batch_active) return;
     Slot<NW> s = slots[i];
@@ -624,6 +631,9 @@ SearchCfg to_cfg(const ArSearchConfig& c, uint32_t sims, uint32_t batch) {
     s.coll_power = c.collision_scaling_power;
     s.n_sims = sims;
     s.batch_size = batch;
+    s.alloc_per_round = 2;  // measured best on the bench workload; results do not depend on it
+    if (const char* e = getenv("AR_ALLOC_PER_ROUND"))
+        if (atoi(e) >= 1) s.alloc_per_round = (uint32_t)atoi(e);
     return s;
 }
 
@@ -803,6 +813,8 @@ struct Engine {
     PinBuf<PosRec<NW>> h_staging;
     std::vector<void*> slot_grown;  // per slot: the arena the host allocated after a stall (nullptr = none)
     ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
+    uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
+    uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
     DevBuf<int> pool_ctr;
@@ -949,12 +961,13 @@ struct Engine {
     }
 
     void launch_gather(bool to_queue) {
-        hipLaunchKernelGGL(k_gather<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(),
-                           to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_gather<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
+                           to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr,
+                           gather_rounds, lanes);
     }
     void launch_backup(bool from_queue) {
-        hipLaunchKernelGGL(k_backup<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
-                           from_queue ? ev_queue.p : (const EvalOut*)nullptr);
+        hipLaunchKernelGGL(k_backup<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
+                           zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes);
     }
     void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg); }
     void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
@@ -1264,6 +1277,10 @@ int parse_device(const char* device, int device_index, int& out) {
 // ------------------------------------------------------------------------------------------------
 // self-play driver
 // ------------------------------------------------------------------------------------------------
+// Round limit of one gather launch: a few rounds per wanted descent covers the typical batch (a
+// descent is one round per tree level) and cuts the long tail; measured in DESIGN.md section 7.
+static uint32_t default_gather_rounds(const SearchCfg&) { return 0xFFFFFFFFu; }
+
 template <int NW>
 int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress* progress, ArGameSink sink,
                   void* sink_user, ArSelfPlayStats* out) {
@@ -1336,6 +1353,11 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
     if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr, pool_bytes)) return rc;
     tm[0] = since(tp);
+    // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
+    eng.gather_rounds = default_gather_rounds(cfg);
+    if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
+    if (const char* e = getenv("AR_LANES_PER_WAVE"))
+        if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
 
     BundleSink writer;
     const bool to_disk = p.output_dir != nullptr;

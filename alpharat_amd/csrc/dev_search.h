@@ -69,6 +69,7 @@ struct SearchCfg {
     uint32_t coll_min, coll_max, coll_start, coll_end;
     float coll_power;
     uint32_t n_sims, batch_size;
+    uint32_t alloc_per_round;  // scheduling only: allocation-loop steps one gather round runs (gather_round)
 };
 
 enum { SLOT_EMPTY = 0, SLOT_ACTIVE = 1, SLOT_DONE = 2, SLOT_STALL = 3, SLOT_FAILED = 4, SLOT_ADVANCE = 5 };
@@ -141,7 +142,7 @@ struct Slot {
     uint64_t nv_gather, nv_backup, new_nodes;
     MoveResult last;  // result of the last finished search
     uint32_t error;   // non-zero: internal capacity violation (bug guard)
-    uint32_t pad0;
+    uint32_t gather_pending;  // 1: a gather was cut off at the round limit, its lane state is in Mem::glane
 };
 
 // resolved addresses of one game's memory (built per kernel from kernel arguments + slot offsets)
@@ -156,6 +157,7 @@ struct Mem {
     EvalOut* ev_local;      // [batch_size] evaluator outputs when the evaluator runs inline
     State<NW>* leaf_local;  // [batch_size] leaf positions for evaluators outside the walk
     PosRec<NW>* pos;        // [max_turns]
+    void* glane;            // GatherLane<NW> of a gather cut off at the round limit
     const uint8_t* cost;    // this game's maze
     uint32_t coll_cap, max_depth;
 };
@@ -395,15 +397,19 @@ AR_HD void half_take(HalfAlloc& h, uint32_t b, uint32_t k) {
     }
 }
 
+// (selects over all 13 words, never a conditional access: a conditional one is turned into a
+// dynamically indexed access by the optimizer, which forces the whole lane state into scratch memory)
 AR_HD uint32_t vtp_get(const uint32_t* w, uint32_t idx) {
     uint32_t word = 0;
-    for (uint32_t j = 0; j < 13; ++j)
-        if (j == (idx >> 1)) word = w[j];
+    const uint32_t x = idx >> 1;
+#pragma unroll
+    for (uint32_t j = 0; j < 13; ++j) word |= (j == x) ? w[j] : 0u;
     return (word >> (16 * (idx & 1u))) & 0xffffu;
 }
 AR_HD void vtp_add(uint32_t* w, uint32_t idx, uint32_t k) {
-    for (uint32_t j = 0; j < 13; ++j)
-        if (j == (idx >> 1)) w[j] += k << (16 * (idx & 1u));
+    const uint32_t x = idx >> 1, v = k << (16 * (idx & 1u));
+#pragma unroll
+    for (uint32_t j = 0; j < 13; ++j) w[j] += (j == x) ? v : 0u;
 }
 
 AR_HD int lowest_bit(uint32_t m) {
@@ -518,6 +524,8 @@ struct GatherLane {
     bool have_pick, enter_root;
     int eval_mode;
     State<NW> work;        // position at the current node
+    uint32_t alloc_left;   // visits of the current node still to allocate (0: not in an allocation)
+    HalfAlloc h1, h2;      // allocation state of the current node
 };
 
 // Starts one simulate_batch. Returns false when the arena cannot take a full batch (the slot
@@ -550,167 +558,183 @@ AR_HD bool gather_begin(GatherLane<NW>& g, Slot<NW>& s, const SearchCfg& cfg, in
     g.enter_root = false;
     g.eval_mode = eval_mode;
     g.work = s.st;
+    g.alloc_left = 0;
     return true;
 }
 
-// One round of a lane's gather. Every lane that is not done runs the same sequence, so the wavefront
-// does not split by state:
-//   1. decide: pop a finished level (rare: only after a split allocation), start the next
-//      pick_nodes_to_extend call at the root, or take the next child slot of the current node
-//      (step the position, one load of the child id; a missing child is created and becomes a leaf
-//      right here, stores only);
-//   2. load the whole record of the node to look at -- the root or the existing child -- in one
-//      round trip and classify it: unvisited / terminal -> claim it as a batch entry (or collision);
-//      visited interior -> add the virtual loss, keep the level if siblings still wait, and expand
-//      it from the registers just loaded: scores, allocation loop, virtual-loss write-back.
-// So a descent costs one round (<= two dependent memory trips) per tree level.
+// One round of a lane's gather. Every lane that is not done runs the same two-part sequence, so the
+// wavefront does not split by state:
+//   D. (lanes not in the middle of an allocation) decide: pop a finished level (rare: only after a
+//      split allocation), start the next pick_nodes_to_extend call at the root, or take the next child
+//      slot of the current node (step the position, one load of the child id; a missing child is
+//      created and becomes a leaf right here, stores only). Then load the whole record of the node to
+//      look at -- the root or the existing child -- in one round trip and classify it: unvisited /
+//      terminal -> a batch entry (or collision); visited interior -> add the virtual loss, keep the
+//      level if siblings still wait, set up the allocation from the registers just loaded. The batch
+//      entry / collision record of whichever branch produced one is written once, after the branches.
+//   A. (lanes with visits still to allocate, including those that just set one up) at most
+//      cfg.alloc_per_round steps of the allocation loop (search.rs:775-798); the virtual-loss
+//      write-back when the last visit is placed.
+// The allocation loop of a node takes 1..batch steps (the root takes the most), so running it to the
+// end inside one round made every lane of the wavefront wait for the longest one; with the cap a
+// long allocation spreads over a few rounds and only that lane waits.
+// A descent costs one round (<= two dependent memory trips) per tree level.
+enum { PROC_NONE = 0xFFu };
 template <int NW>
 AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     if (g.state == G_DONE) return;
-    uint32_t rec = NIL;       // node whose record is inspected in step 2
-    uint32_t visits_in = 0;   // visits routed to it (pick budget or k)
-    bool from_pick = false;
-    State<NW> before = g.work;
-    if (g.mask == 0 && g.depth > 0) {
-        // level exhausted: backtrack (search.rs:728-734)
-        g.depth -= 1;
-        const Level<NW>& L = m.levels[g.depth];
-        g.node = L.node;
-        g.mask = L.mask;
-        g.omap0 = L.omap[0];
-        g.omap1 = L.omap[1];
-        for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
-        g.work = L.saved;
-        return;
-    }
-    if (g.mask == 0) {
-        // search.rs:981-999 outer gather loop around pick_nodes_to_extend
-        if (g.have_pick) {
-            s.b_coll += g.pick_mv;
-            g.left -= (long long)g.pick_mv;
-            g.have_pick = false;
-        }
-        if (!(s.n_proc < g.batch && g.left > 0)) {
-            g.state = G_DONE;
-            s.batch_active = 1;
-            return;
-        }
-        uint32_t budget = (uint32_t)g.left;
-        if (g.batch - s.n_proc < budget) budget = g.batch - s.n_proc;
-        g.pick_mv = 0;
-        g.have_pick = true;
-        g.work = s.st;
-        before = g.work;
-        rec = s.root;
-        visits_in = budget;
-        from_pick = true;
-    } else {
-        const uint32_t idx = (uint32_t)lowest_bit(g.mask);
-        g.mask &= g.mask - 1;
-        const uint32_t k = vtp_get(g.vtp, idx);
-        const uint32_t o1 = idx / 5, o2 = idx % 5;
-        float r1, r2;
-        st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
-        const uint32_t child = m.kids[g.node].c[idx];
-        if (child == NIL) {
-            // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
-            if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
-                s.error = 3;
-            } else {
-                const uint32_t nid = s.hi++;
-                init_shell(m.stats[nid], m.kids[nid], eff_actions(m.cost, g.work.p1, g.work.m1),
-                           eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
-                m.kids[g.node].c[idx] = nid;
-                s.node_count += 1;
-                s.new_nodes += 1;
-                m.stats[nid].h0.nif = 1;  // try_start_score_update on a fresh node
-                emit_proc(s, m, cfg, g.eval_mode, nid, st_over(s.board, g.work) ? PROC_TERMINAL : PROC_EVAL, g.work);
-                if (st_over(s.board, g.work)) m.stats[nid].h2.terminal = 1;
-                if (k > 1) emit_coll(s, m, nid, k - 1, g.pick_mv);
-            }
-            g.work = before;
-            return;
-        }
-        rec = child;
-        visits_in = k;
-    }
-
-    // ---- step 2: the record of `rec`, one round trip ------------------------------------------
-    const NodeStats& N = m.stats[rec];
-    Edge e1[5], e2[5];
-    for (int i = 0; i < 5; ++i) {
-        e1[i] = N.e[0][i];
-        e2[i] = N.e[1][i];
-    }
-    const NodeH0 a = N.h0;
-    const NodeH1 b = N.h1;
-    const NodeH2 c = N.h2;
-    if (a.visits == 0 || c.terminal != 0) {
-        // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
-        if (!(a.visits == 0 && a.nif > 0)) {  // try_start_score_update
-            m.stats[rec].h0.nif = a.nif + 1;
-            if (c.terminal != 0 || st_over(s.board, g.work)) {
-                if (a.visits == 0) m.stats[rec].h2.terminal = 1;
-                emit_proc(s, m, cfg, g.eval_mode, rec, PROC_TERMINAL, g.work);
-            } else {
-                emit_proc(s, m, cfg, g.eval_mode, rec, PROC_EVAL, g.work);
-            }
-            if (visits_in > 1) emit_coll(s, m, rec, visits_in - 1, g.pick_mv);
+    if (g.alloc_left == 0) {
+        const State<NW> before = g.work;
+        if (g.mask == 0 && g.depth > 0) {
+            // level exhausted: backtrack (search.rs:728-734)
+            g.depth -= 1;
+            const Level<NW>& L = m.levels[g.depth];
+            g.node = L.node;
+            g.mask = L.mask;
+            g.omap0 = L.omap[0];
+            g.omap1 = L.omap[1];
+            for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
+            g.work = L.saved;
         } else {
-            emit_coll(s, m, rec, visits_in, g.pick_mv);
+            uint32_t rec = NIL;      // node whose record is inspected
+            uint32_t visits_in = 0;  // visits routed to it (pick budget or k)
+            bool from_pick = false;
+            uint32_t emit_node = NIL, emit_kind = PROC_NONE, coll_mv = 0;
+            bool restore = false;
+            if (g.mask == 0) {
+                // search.rs:981-999 outer gather loop around pick_nodes_to_extend
+                if (g.have_pick) {
+                    s.b_coll += g.pick_mv;
+                    g.left -= (long long)g.pick_mv;
+                    g.have_pick = false;
+                }
+                if (!(s.n_proc < g.batch && g.left > 0)) {
+                    g.state = G_DONE;
+                    s.batch_active = 1;
+                    return;
+                }
+                uint32_t budget = (uint32_t)g.left;
+                if (g.batch - s.n_proc < budget) budget = g.batch - s.n_proc;
+                g.pick_mv = 0;
+                g.have_pick = true;
+                g.work = s.st;
+                rec = s.root;
+                visits_in = budget;
+                from_pick = true;
+            } else {
+                const uint32_t idx = (uint32_t)lowest_bit(g.mask);
+                g.mask &= g.mask - 1;
+                const uint32_t k = vtp_get(g.vtp, idx);
+                const uint32_t o1 = idx / 5, o2 = idx % 5;
+                float r1, r2;
+                st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
+                const uint32_t child = m.kids[g.node].c[idx];
+                if (child == NIL) {
+                    // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
+                    if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
+                        s.error = 3;
+                    } else {
+                        const uint32_t nid = s.hi++;
+                        init_shell(m.stats[nid], m.kids[nid], eff_actions(m.cost, g.work.p1, g.work.m1),
+                                   eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
+                        m.kids[g.node].c[idx] = nid;
+                        s.node_count += 1;
+                        s.new_nodes += 1;
+                        m.stats[nid].h0.nif = 1;  // try_start_score_update on a fresh node
+                        const bool over = st_over(s.board, g.work);
+                        if (over) m.stats[nid].h2.terminal = 1;
+                        emit_node = nid;
+                        emit_kind = over ? PROC_TERMINAL : PROC_EVAL;
+                        coll_mv = k > 1 ? k - 1 : 0;
+                    }
+                    restore = true;
+                } else {
+                    rec = child;
+                    visits_in = k;
+                }
+            }
+            if (rec != NIL) {
+                // the record of `rec`, one round trip
+                const NodeStats& N = m.stats[rec];
+                Edge e1[5], e2[5];
+                for (int i = 0; i < 5; ++i) {
+                    e1[i] = N.e[0][i];
+                    e2[i] = N.e[1][i];
+                }
+                const NodeH0 a = N.h0;
+                const NodeH1 b = N.h1;
+                const NodeH2 c = N.h2;
+                if (a.visits == 0 || c.terminal != 0) {
+                    // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
+                    emit_node = rec;
+                    if (!(a.visits == 0 && a.nif > 0)) {  // try_start_score_update
+                        m.stats[rec].h0.nif = a.nif + 1;
+                        const bool term = c.terminal != 0 || st_over(s.board, g.work);
+                        if (term && a.visits == 0) m.stats[rec].h2.terminal = 1;
+                        emit_kind = term ? PROC_TERMINAL : PROC_EVAL;
+                        coll_mv = visits_in > 1 ? visits_in - 1 : 0;
+                    } else {
+                        coll_mv = visits_in;
+                    }
+                    restore = true;  // (a root pick leaves work == s.st; mask stays 0 -> next round picks again)
+                } else if (!from_pick && g.depth >= m.max_depth) {
+                    s.error = 4;
+                    restore = true;
+                } else {
+                    // visited interior node: route the visits through it (search.rs:639 / :707-725)
+                    m.stats[rec].h0.nif = a.nif + visits_in;
+                    if (!from_pick && g.mask != 0) {  // siblings still wait: keep the parent level for the way back
+                        Level<NW>& L = m.levels[g.depth];
+                        L.node = g.node;
+                        L.mask = g.mask;
+                        L.omap[0] = g.omap0;
+                        L.omap[1] = g.omap1;
+                        for (int j = 0; j < 13; ++j) L.vtp[j] = g.vtp[j];
+                        L.saved = before;
+                        g.depth += 1;
+                    }
+                    if (from_pick) g.depth = 0;
+                    // set up build_gather_level (search.rs:742-817) from the registers just loaded
+                    const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
+                    half_init(g.h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, from_pick);
+                    half_init(g.h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, from_pick);
+                    g.node = rec;
+                    g.omap0 = c.omap[0];
+                    g.omap1 = c.omap[1];
+                    g.mask = 0;
+                    for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
+                    s.nv_gather += 1;
+                    g.alloc_left = visits_in;
+                }
+            }
+            if (emit_kind != PROC_NONE) emit_proc(s, m, cfg, g.eval_mode, emit_node, emit_kind, g.work);
+            if (coll_mv) emit_coll(s, m, emit_node, coll_mv, g.pick_mv);
+            if (restore) g.work = before;
         }
-        g.work = before;  // (a root pick leaves work == s.st; mask stays 0 -> next round picks again)
-        return;
     }
-    if (!from_pick && g.depth >= m.max_depth) {
-        s.error = 4;
-        g.work = before;
-        return;
-    }
-    // visited interior node: route the visits through it (search.rs:639 / :707-725)
-    m.stats[rec].h0.nif = a.nif + visits_in;
-    if (!from_pick && g.mask != 0) {  // siblings still wait: keep the parent level for the way back
-        Level<NW>& L = m.levels[g.depth];
-        L.node = g.node;
-        L.mask = g.mask;
-        L.omap[0] = g.omap0;
-        L.omap[1] = g.omap1;
-        for (int j = 0; j < 13; ++j) L.vtp[j] = g.vtp[j];
-        L.saved = before;
-        g.depth += 1;
-    }
-    if (from_pick) g.depth = 0;
-    // expand `rec` (search.rs:742-817 build_gather_level) from the registers just loaded
-    const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
-    HalfAlloc h1, h2;
-    half_init(h1, e1, meta_n(c.meta, 0), a.v1, b.scale, cv, cfg, from_pick);
-    half_init(h2, e2, meta_n(c.meta, 1), a.v2, b.scale, cv, cfg, from_pick);
-    g.node = rec;
-    g.omap0 = c.omap[0];
-    g.omap1 = c.omap[1];
-    g.mask = 0;
-    for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
-    s.nv_gather += 1;
-    uint32_t remaining = visits_in;
-    while (remaining > 0) {  // search.rs:775-798, no memory traffic in this loop
-        uint32_t b1, b2, c1, c2;
-        half_best(h1, s.rng, b1, c1);
-        half_best(h2, s.rng, b2, c2);
-        uint32_t k = remaining;
-        if (c1 < k) k = c1;
-        if (c2 < k) k = c2;
-        if (k < 1) k = 1;
-        const uint32_t flat = b1 * 5 + b2;
-        vtp_add(g.vtp, flat, k);
-        g.mask |= 1u << flat;
-        half_take(h1, b1, k);
-        half_take(h2, b2, k);
-        remaining -= k;
-    }
-    NodeStats& W = m.stats[rec];  // search.rs:800-814: write the virtual-loss deltas back
-    for (uint32_t i = 0; i < 5; ++i) {
-        if (h1.add[i]) W.e[0][i].nif = h1.nif0[i] + h1.add[i];
-        if (h2.add[i]) W.e[1][i].nif = h2.nif0[i] + h2.add[i];
+    if (g.alloc_left > 0) {
+        for (uint32_t it = 0; it < cfg.alloc_per_round && g.alloc_left > 0; ++it) {  // search.rs:775-798, no memory traffic
+            uint32_t b1, b2, c1, c2;
+            half_best(g.h1, s.rng, b1, c1);
+            half_best(g.h2, s.rng, b2, c2);
+            uint32_t k = g.alloc_left;
+            if (c1 < k) k = c1;
+            if (c2 < k) k = c2;
+            if (k < 1) k = 1;
+            const uint32_t flat = b1 * 5 + b2;
+            vtp_add(g.vtp, flat, k);
+            g.mask |= 1u << flat;
+            half_take(g.h1, b1, k);
+            half_take(g.h2, b2, k);
+            g.alloc_left -= k;
+        }
+        if (g.alloc_left == 0) {
+            NodeStats& W = m.stats[g.node];  // search.rs:800-814: write the virtual-loss deltas back
+            for (uint32_t i = 0; i < 5; ++i) {
+                if (g.h1.add[i]) W.e[0][i].nif = g.h1.nif0[i] + g.h1.add[i];
+                if (g.h2.add[i]) W.e[1][i].nif = g.h2.nif0[i] + g.h2.add[i];
+            }
+        }
     }
 }
 
@@ -725,6 +749,35 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
         if (g.state == run) gather_round(g, s, m, cfg);
     }
     return ok;
+}
+
+// The same with a limit on the rounds one call may run. The time of a gather kernel is the time of
+// its slowest lane, and the number of rounds a batch takes varies several-fold between games, so
+// without a limit most lanes sit finished while a few complete theirs. A lane that hits the limit
+// parks its state in the slot's scratch and resumes at the next call; only complete batches go on to
+// the evaluator and the backup. Per-game results do not depend on where the cuts fall.
+enum { GATHER_STALLED = 0, GATHER_COMPLETE = 1, GATHER_PENDING = 2 };
+template <int NW>
+AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode,
+                                 uint32_t max_rounds) {
+    GatherLane<NW> g;
+    GatherLane<NW>* parked = (GatherLane<NW>*)m.glane;
+    bool ok = true;
+    if (s.gather_pending) g = *parked;
+    else ok = gather_begin(g, s, cfg, eval_mode);
+    for (uint32_t r = 0; r < max_rounds; ++r) {
+        const uint32_t run = elect_state(g.state, G_DONE, G_DONE);
+        if (run == G_DONE) break;
+        if (g.state == run) gather_round(g, s, m, cfg);
+    }
+    if (!ok) return GATHER_STALLED;
+    if (g.state != G_DONE) {
+        *parked = g;
+        s.gather_pending = 1;
+        return GATHER_PENDING;
+    }
+    s.gather_pending = 0;
+    return GATHER_COMPLETE;
 }
 
 // ---- backup: search.rs:1027-1066 ---------------------------------------------------------------
@@ -1187,6 +1240,7 @@ AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     s.b_nn = s.b_term = s.b_coll = 0;
     s.batch_active = 0;
     s.error = 0;
+    s.gather_pending = 0;
     s.remaining = cfg.n_sims;
     make_root(s, m);
     if (!s.single_search && st_over(s.board, s.st)) s.status = SLOT_DONE;  // while !check_game_over()

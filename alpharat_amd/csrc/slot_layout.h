@@ -7,7 +7,7 @@
 namespace ar {
 
 struct SlotLayout {
-    size_t proc_off, coll_off, levels_off, ev_off, leaf_off, pos_off, total;
+    size_t proc_off, coll_off, levels_off, ev_off, leaf_off, pos_off, glane_off, total;
     uint32_t coll_cap, max_depth;
 };
 
@@ -30,7 +30,9 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     L.leaf_off = off;
     off = align_up(off + sizeof(State<NW>) * cfg.batch_size, 64);
     L.pos_off = off;
-    off = align_up(off + sizeof(PosRec<NW>) * (max_turns > 0 ? max_turns : 1), 256);
+    off = align_up(off + sizeof(PosRec<NW>) * (max_turns > 0 ? max_turns : 1), 64);
+    L.glane_off = off;
+    off = align_up(off + sizeof(GatherLane<NW>), 256);
     L.total = off;
     return L;
 }
@@ -52,6 +54,7 @@ AR_HD Mem<NW> resolve_mem(const Slot<NW>& s, unsigned char* arena_base, unsigned
     m.ev_local = (EvalOut*)(base + L.ev_off);
     m.leaf_local = (State<NW>*)(base + L.leaf_off);
     m.pos = (PosRec<NW>*)(base + L.pos_off);
+    m.glane = (void*)(base + L.glane_off);
     m.cost = maze_pool + s.board.maze_off;
     m.coll_cap = L.coll_cap;
     m.max_depth = L.max_depth;

@@ -59,6 +59,7 @@ static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
     s.coll_power = c->coll_power;
     s.n_sims = n_sims;
     s.batch_size = batch;
+    s.alloc_per_round = 2;
     return s;
 }
 
@@ -85,11 +86,14 @@ static void grow(HsRun* r) {
 }
 
 // eval_mode 0: SmartUniform inline; 1: leaves stored, harness evaluates (uniform priors + constant
-// values v1/v2) -- exercises the split gather / evaluate / backup path.
+// values v1/v2) -- exercises the split gather / evaluate / backup path; 3: the same with the gather
+// limited to 7 rounds per call (gather_machine_limited).
 void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, uint64_t seed, int single,
              int eval_mode, float v1, float v2, uint32_t arena_nodes) {
     HsRun* r = new HsRun();
     r->cfg = to_cfg(c, n_sims, batch);
+    // scheduling knob only: vary it across the modes so every cut position of the allocation loop is exercised
+    r->cfg.alloc_per_round = eval_mode == 3 ? 1 : eval_mode == 1 ? 3 : 2;
     const int hw = g->width * g->height;
     r->cost.assign(g->cost, g->cost + hw * 4);
     r->L = make_layout<4>(r->cfg, g->max_turns);
@@ -138,7 +142,10 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
             fused_machine(s, m, r->cfg, &g_zig, 3);
             continue;
         }
-        if (!gather_machine(s, m, r->cfg, mode)) continue;
+        if (eval_mode == 3) {  // the self-play kernel's gather: cut off every few rounds, parked, resumed
+            const int got = gather_machine_limited(s, m, r->cfg, mode, 7);
+            if (got != GATHER_COMPLETE) continue;
+        } else if (!gather_machine(s, m, r->cfg, mode)) continue;
         const EvalOut* evp = m.ev_local;
         if (eval_mode != 0) {
             for (uint32_t j = 0; j < s.b_nn; ++j) {

@@ -74,6 +74,8 @@ def test_whole_game_tuned_noise_7x7_and_split_eval_path():
     _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=1))
     # the fused multi-batch machine of the SmartUniform step kernel, same answers
     _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=2))
+    # gather cut off every 7 rounds and resumed from its parked lane state
+    _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=3))
 
 
 def test_arena_growth_keeps_results():
