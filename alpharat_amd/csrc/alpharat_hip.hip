@@ -199,11 +199,10 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
 template <int NW>
 __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t max_rounds,
-                                               uint32_t lanes) {
-    // `lanes` games per wavefront (<= 64): fewer games per wave means more waves per SIMD to hide the
-    // dependent loads behind and fewer divergent paths per instruction stream
+                                               uint32_t lanes, uint32_t first) {
+    // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64)
     if (threadIdx.x >= lanes) return;
-    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
+    const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE) return;
     Slot<NW> s = slots[i];
@@ -226,9 +225,10 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
 
 template <int NW>
 __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
-                                               const ZigTables* zt, const EvalOut* ev_queue, uint32_t lanes) {
+                                               const ZigTables* zt, const EvalOut* ev_queue, uint32_t lanes,
+                                               uint32_t first) {
     if (threadIdx.x >= lanes) return;
-    const uint32_t i = blockIdx.x * lanes + threadIdx.x;
+    const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     if (slots[i].status != SLOT_ACTIVE || !slots[i].batch_active) return;
     Slot<NW> s = slots[i];
@@ -248,8 +248,9 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
 // and a tree that shrank gives its block back. A slot that stalled anyway (pool empty at the time)
 // is retried here on every launch: its nodes are copied unchanged into a bigger block.
 template <int NW>
-__global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B, SearchCfg cfg) {
-    const uint32_t slot = blockIdx.x;
+__global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B, SearchCfg cfg,
+                                                uint32_t first_slot) {
+    const uint32_t slot = first_slot + blockIdx.x;
     if (slot >= n_slots) return;
     const uint32_t status = slots[slot].status;
     if (status != SLOT_ADVANCE && status != SLOT_STALL) return;
@@ -827,6 +828,13 @@ struct Engine {
 
     ~Engine() {
         if (stream) hipStreamSynchronize(stream);
+        for (Group& g : groups) {
+            if (g.stream && g.stream != stream) {
+                hipStreamSynchronize(g.stream);
+                hipStreamDestroy(g.stream);
+            }
+            if (g.done) hipEventDestroy(g.done);
+        }
         for (void* p : slot_grown)
             if (p) hipFree(p);
         if (ev0) hipEventDestroy(ev0);
@@ -928,7 +936,7 @@ struct Engine {
         if (need_queue) {
             HIP_TRY(queue.alloc((size_t)S * cfg.batch_size));
             HIP_TRY(ev_queue.alloc((size_t)S * cfg.batch_size));
-            HIP_TRY(queue_count.alloc(1));
+            HIP_TRY(queue_count.alloc(64));
         }
         if (net != nullptr) {
             const size_t per = (size_t)net->dev.hw * 4;
@@ -960,16 +968,57 @@ struct Engine {
         return AR_OK;
     }
 
+    // Games are split into `n_groups` contiguous slot ranges, each with its own stream and evaluator
+    // queue. The groups run the same gather -> evaluate -> backup -> advance sequence independently, so
+    // the compute-bound network kernel of one group overlaps the latency-bound tree walks of the others.
+    struct Group {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        uint32_t first = 0, end = 0;  // slots [first, end)
+    };
+    std::vector<Group> groups;
+    int make_groups(uint32_t n) {
+        if (n < 1) n = 1;
+        if (n > S) n = S;
+        groups.resize(n);
+        for (uint32_t g = 0; g < n; ++g) {
+            groups[g].first = (uint32_t)((uint64_t)S * g / n);
+            groups[g].end = (uint32_t)((uint64_t)S * (g + 1) / n);
+            if (n > 1) {
+                HIP_TRY(hipStreamCreateWithFlags(&groups[g].stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&groups[g].done, hipEventDisableTiming));
+            } else {
+                groups[g].stream = stream;
+            }
+        }
+        return AR_OK;
+    }
+    int group_step(const Group& g) {
+        const uint32_t n = g.end - g.first, gi = (uint32_t)(&g - groups.data());
+        LeafReq<NW>* q = queue.p + (size_t)g.first * cfg.batch_size;
+        EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
+        uint32_t* qc = queue_count.p + gi;
+        HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
+        hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                           qc, gather_rounds, lanes, g.first);
+        if (int rc = net_forward_queue<NW>(net, q, qc, (uint32_t)((size_t)n * cfg.batch_size), slots.p, maze.p, ev, g.stream))
+            return rc;
+        hipLaunchKernelGGL(k_backup<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(),
+                           zig.p, ev, lanes, g.first);
+        hipLaunchKernelGGL(k_advance<NW>, dim3(n), dim3(64), 0, g.stream, slots.p, g.end, bases(), cfg, g.first);
+        return AR_OK;
+    }
+
     void launch_gather(bool to_queue) {
         hipLaunchKernelGGL(k_gather<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
                            to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr,
-                           gather_rounds, lanes);
+                           gather_rounds, lanes, 0u);
     }
     void launch_backup(bool from_queue) {
         hipLaunchKernelGGL(k_backup<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
-                           zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes);
+                           zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes, 0u);
     }
-    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg); }
+    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg, 0u); }
     void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
 
     // `n_launch` rounds of {`iters` simulate_batch per game, then tree reuse for the games that moved},
@@ -983,17 +1032,23 @@ struct Engine {
                 launch_advance();
                 steps += (uint64_t)iters;
             } else {
-                for (int it = 0; it < iters; ++it) {
-                    HIP_TRY(hipMemsetAsync(queue_count.p, 0, 4, stream));
-                    launch_gather(true);
-                    int rc = net_forward_queue<NW>(net, queue.p, queue_count.p, (uint32_t)((size_t)S * cfg.batch_size),
-                                                   slots.p, maze.p, ev_queue.p, stream);
-                    if (rc != AR_OK) return rc;
-                    launch_backup(true);
-                    launch_advance();
-                    steps += 1;
-                }
+                steps += (uint64_t)iters;
             }
+        }
+        if (net != nullptr) {
+            if (groups.empty())
+                if (int rc = make_groups(1)) return rc;
+            const bool multi = groups.size() > 1;
+            if (multi)
+                for (const Group& g : groups) HIP_TRY(hipStreamWaitEvent(g.stream, ev0, 0));
+            for (int k = 0; k < n_launch * iters; ++k)
+                for (const Group& g : groups)
+                    if (int rc = group_step(g)) return rc;
+            if (multi)
+                for (const Group& g : groups) {
+                    HIP_TRY(hipEventRecord(g.done, g.stream));
+                    HIP_TRY(hipStreamWaitEvent(stream, g.done, 0));
+                }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));
@@ -1356,6 +1411,13 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
     eng.gather_rounds = default_gather_rounds(cfg);
     if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
+    {
+        // groups of games pipelined against each other (Engine::group_step); AR_GROUPS overrides
+        uint32_t ng = (net != nullptr && S >= 4096) ? 4u : 1u;  // small runs: nothing to overlap
+        if (const char* e = getenv("AR_GROUPS"))
+            if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
+        if (int rc = eng.make_groups(ng)) return rc;
+    }
     if (const char* e = getenv("AR_LANES_PER_WAVE"))
         if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
 
@@ -1694,6 +1756,13 @@ int ar_debug_round_stats(unsigned long long* out32) {
     HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ar::g_round_stats), sizeof(unsigned long long) * 32));
     unsigned long long z[32] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ar::g_round_stats), z, sizeof z));
+    return AR_OK;
+}
+int ar_debug_gather_hist(unsigned long long* out136) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out136, HIP_SYMBOL(ar::g_gather_hist), sizeof(unsigned long long) * 136));
+    unsigned long long z[136] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ar::g_gather_hist), z, sizeof z));
     return AR_OK;
 }
 #endif

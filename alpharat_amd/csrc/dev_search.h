@@ -434,6 +434,12 @@ enum {
 // sequence of states -- and therefore its result -- does not depend on the election.
 #if defined(AR_STATS) && defined(__HIPCC__)
 __device__ unsigned long long g_round_stats[32];  // [machine*16 + state*2 + {rounds, lanes}] , [30] alive, [31] rounds
+// [0..63] lanes by rounds/4 of one gather, [64..127] wavefronts by (max rounds)/4, [128..135] lane-rounds by
+// path: pop, pick, new leaf, leaf claim, interior, allocation steps, rounds in allocation only, done-at-pick
+__device__ unsigned long long g_gather_hist[136];
+#define AR_COUNT(i) atomicAdd(&g_gather_hist[i], 1ULL)
+#else
+#define AR_COUNT(i) ((void)0)
 #endif
 AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_state, uint32_t machine = 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -583,10 +589,14 @@ enum { PROC_NONE = 0xFFu };
 template <int NW>
 AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     if (g.state == G_DONE) return;
+#if defined(AR_STATS) && defined(__HIPCC__)
+    if (g.alloc_left != 0) AR_COUNT(134);
+#endif
     if (g.alloc_left == 0) {
         const State<NW> before = g.work;
         if (g.mask == 0 && g.depth > 0) {
             // level exhausted: backtrack (search.rs:728-734)
+            AR_COUNT(128);
             g.depth -= 1;
             const Level<NW>& L = m.levels[g.depth];
             g.node = L.node;
@@ -609,10 +619,12 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                     g.have_pick = false;
                 }
                 if (!(s.n_proc < g.batch && g.left > 0)) {
+                    AR_COUNT(135);
                     g.state = G_DONE;
                     s.batch_active = 1;
                     return;
                 }
+                AR_COUNT(129);
                 uint32_t budget = (uint32_t)g.left;
                 if (g.batch - s.n_proc < budget) budget = g.batch - s.n_proc;
                 g.pick_mv = 0;
@@ -631,6 +643,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const uint32_t child = m.kids[g.node].c[idx];
                 if (child == NIL) {
                     // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
+                    AR_COUNT(130);
                     if (s.hi >= s.cap) {  // excluded by the capacity check in gather_begin
                         s.error = 3;
                     } else {
@@ -666,6 +679,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const NodeH2 c = N.h2;
                 if (a.visits == 0 || c.terminal != 0) {
                     // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
+                    AR_COUNT(131);
                     emit_node = rec;
                     if (!(a.visits == 0 && a.nif > 0)) {  // try_start_score_update
                         m.stats[rec].h0.nif = a.nif + 1;
@@ -682,6 +696,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                     restore = true;
                 } else {
                     // visited interior node: route the visits through it (search.rs:639 / :707-725)
+                    AR_COUNT(132);
                     m.stats[rec].h0.nif = a.nif + visits_in;
                     if (!from_pick && g.mask != 0) {  // siblings still wait: keep the parent level for the way back
                         Level<NW>& L = m.levels[g.depth];
@@ -714,6 +729,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
     }
     if (g.alloc_left > 0) {
         for (uint32_t it = 0; it < cfg.alloc_per_round && g.alloc_left > 0; ++it) {  // search.rs:775-798, no memory traffic
+            AR_COUNT(133);
             uint32_t b1, b2, c1, c2;
             half_best(g.h1, s.rng, b1, c1);
             half_best(g.h2, s.rng, b2, c2);
@@ -765,11 +781,27 @@ AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg&
     bool ok = true;
     if (s.gather_pending) g = *parked;
     else ok = gather_begin(g, s, cfg, eval_mode);
+    uint32_t my_rounds = 0;
     for (uint32_t r = 0; r < max_rounds; ++r) {
         const uint32_t run = elect_state(g.state, G_DONE, G_DONE);
         if (run == G_DONE) break;
-        if (g.state == run) gather_round(g, s, m, cfg);
+        if (g.state == run) {
+            gather_round(g, s, m, cfg);
+            my_rounds += 1;
+        }
     }
+#if defined(AR_STATS) && defined(__HIPCC__)
+    {
+        uint32_t wave_max = my_rounds;
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)wave_max, off, 64);
+            wave_max = o > wave_max ? o : wave_max;
+        }
+        if (ok) atomicAdd(&g_gather_hist[my_rounds / 4 < 63 ? my_rounds / 4 : 63], 1ULL);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_gather_hist[64 + (wave_max / 4 < 63 ? wave_max / 4 : 63)], 1ULL);
+    }
+#endif
+    (void)my_rounds;
     if (!ok) return GATHER_STALLED;
     if (g.state != G_DONE) {
         *parked = g;

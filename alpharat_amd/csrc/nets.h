@@ -162,6 +162,46 @@ __device__ inline void dense_acc(const float* __restrict__ wt, int K, int H, int
     }
 }
 
+// The same product on the matrix cores for a 32-leaf tile: out[32][H] = relu(bias + act[32][K] x wt[K][H]).
+// v_mfma_f32_32x32x2_f32 accumulates each output element as the k-ordered chain
+// fma(a_k1, b_k1, fma(a_k0, b_k0, c)) with one rounding per product (cdna_hip_programming.md, "FP32-input
+// MFMA"), i.e. bit for bit what dense_acc computes, at twice the VALU rate and with one VGPR per operand.
+// Each wavefront owns column tiles of 32; two tiles share one pass over K (one LDS read of the
+// activations feeds both, two independent accumulator chains cover the weight loads' latency).
+// Operand lanes: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31];
+// result register v of lane l is out[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31].
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ inline void dense_mfma32_relu(const float* __restrict__ wt, const float* __restrict__ bias, int K, int H,
+                                         const float* act, int ld, float* out, int tid, int n_threads) {
+    const int wave = tid >> 6, n_waves = n_threads >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const float* ap = act + (size_t)r * ld + h;
+    for (int n0 = wave * 64; n0 < H; n0 += n_waves * 64) {
+        const bool two = n0 + 32 < H;  // wave-uniform
+        const float* bp0 = wt + (size_t)h * H + n0 + r;
+        const float* bp1 = bp0 + (two ? 32 : 0);
+        f32x16 c0, c1;
+        const float b0 = bias[n0 + r], b1 = bias[n0 + (two ? 32 : 0) + r];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            c0[v] = b0;
+            c1[v] = b1;
+        }
+#pragma unroll 8
+        for (int k = 0; k < K; k += 2) {
+            const float a = ap[k];
+            const float w0 = bp0[(size_t)k * H], w1 = bp1[(size_t)k * H];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+            out[(size_t)i * ld + n0 + r] = fmaxf(c0[v], 0.0f);
+            if (two) out[(size_t)i * ld + n0 + 32 + r] = fmaxf(c1[v], 0.0f);
+        }
+    }
+}
+
 __device__ inline void softmax5(const float* l, float* p) {
     float mx = l[0];
     for (int i = 1; i < 5; ++i) mx = fmaxf(mx, l[i]);
@@ -241,13 +281,18 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
         }
     }
     __syncthreads();
-    for (int nn = tid; nn < H; nn += NTHREADS) {
-        float acc[L];
+    if ((H & 31) == 0 && (H & 1) == 0) {
+        static_assert(L == 32, "the MFMA tile is 32 leaves");
+        dense_mfma32_relu(net.w2t, net.b2, H, H, a1, ld, a2, tid, NTHREADS);
+    } else {
+        for (int nn = tid; nn < H; nn += NTHREADS) {
+            float acc[L];
 #pragma unroll
-        for (int l = 0; l < L; ++l) acc[l] = net.b2[nn];
-        dense_acc<L>(net.w2t, H, H, nn, a1, ld, acc);
+            for (int l = 0; l < L; ++l) acc[l] = net.b2[nn];
+            dense_acc<L>(net.w2t, H, H, nn, a1, ld, acc);
 #pragma unroll
-        for (int l = 0; l < L; ++l) a2[(size_t)l * ld + nn] = fmaxf(acc[l], 0.0f);
+            for (int l = 0; l < L; ++l) a2[(size_t)l * ld + nn] = fmaxf(acc[l], 0.0f);
+        }
     }
     __syncthreads();
     // heads: 12 dot products per leaf

@@ -88,7 +88,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=65536, help="games per GPU per step (all resident at once)")
+    ap.add_argument("--games", type=int, default=262144, help="games per GPU per step")
+    ap.add_argument("--resident", type=int, default=65536,
+                    help="games resident on the GPU at once (one lane each; finished games are replaced from the rest)")
     ap.add_argument("--evaluator", choices=["mlp", "uniform"], default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -124,7 +126,7 @@ def main() -> int:
         # game ids are global and disjoint across ranks and steps; per-GPU work is fixed (weak scaling)
         first = (step_idx * world + rank) * args.games
         return rust_self_play(**GAME, num_games=args.games, simulations=SIMS, batch_size=BATCH, output_dir=None,
-                              weights_path=weights, seed=0, first_game_index=first, concurrent_games=args.games,
+                              weights_path=weights, seed=0, first_game_index=first, concurrent_games=min(args.resident, args.games),
                               device_index=local_rank, **SEARCH)
 
     for w in range(args.warmup):
@@ -186,7 +188,8 @@ def main() -> int:
         "data": "synthetic",
         "config": {"workload": "7x7 open PyRat, 10 cheese, 50 turns, 7x7_rust_tuned (1897 sims, batch 16, noise 0.25), "
                                + ("PyRatMLP h256 random weights" if args.evaluator == "mlp" else "SmartUniform priors"),
-                   "games_per_gpu_per_step": args.games, "parallelism": f"games sharded over {world} GPU(s), no collective"},
+                   "games_per_gpu_per_step": args.games, "resident_games_per_gpu": min(args.resident, args.games),
+                   "parallelism": f"games sharded over {world} GPU(s), no collective"},
         "games_per_sec": tot["games"] / elapsed,
         "nn_evals_per_sec": tot["nn"] / elapsed,
         "descents_per_sec": tot["desc"] / elapsed,

@@ -89,3 +89,32 @@ def test_selfplay_with_device_net_runs_and_is_consistent():
     for g in games:
         assert np.all(np.abs(g["policy_p1"].sum(axis=1) - 1) < 1e-5)
         assert np.all(g["value_p1"] >= 0)  # softplus values, non-negative rewards
+
+
+def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
+    """Groups of games pipelined on separate streams, the gather round limit, the allocation steps per
+    round and the lanes per wavefront only change when work happens, never what a game computes."""
+    from alpharat_amd.sampling import rust_self_play
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        games = []
+        rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=40, simulations=96, batch_size=16,
+                       output_dir=None, seed=5, weights_path=str(GOLD / "nets" / "mlp_7x7_h256.arnet"), concurrent_games=24,
+                       c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, on_game=games.append)
+        for k in env:
+            monkeypatch.delenv(k)
+        return {g["game_index"]: g for g in games}
+
+    base = run(AR_GROUPS=1)
+    for env in (dict(AR_GROUPS=3), dict(AR_GROUPS=2, AR_GATHER_ROUNDS=5), dict(AR_ALLOC_PER_ROUND=1, AR_LANES_PER_WAVE=16),
+                dict(AR_GROUPS=4, AR_ALLOC_PER_ROUND=7, AR_GATHER_ROUNDS=11)):
+        other = run(**env)
+        assert sorted(other) == sorted(base)
+        for i, g in base.items():
+            for key, val in g.items():
+                if isinstance(val, np.ndarray):
+                    np.testing.assert_array_equal(val, other[i][key], err_msg=f"{env} game {i} {key}")
+                else:
+                    assert val == other[i][key], (env, i, key)

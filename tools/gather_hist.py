@@ -1,0 +1,46 @@
+"""Distribution of gather rounds per lane / per wavefront and of the paths lanes take, from the
+instrumented build (hipcc ... -DAR_STATS -o alpharat_amd/libalpharat_hip_stats.so). Bench workload."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from alpharat_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = _lib.PKG / "libalpharat_hip_stats.so"
+import bench  # noqa: E402
+from alpharat_amd.sampling import rust_self_play  # noqa: E402
+
+L = _lib.load()
+games = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+blob = bench.make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet")
+st = rust_self_play(**bench.GAME, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
+                    weights_path=str(blob), seed=0, concurrent_games=games, **bench.SEARCH)
+out = (C.c_ulonglong * 136)()
+L.ar_debug_gather_hist.argtypes = [C.c_void_p]
+L.ar_debug_gather_hist(out)
+o = list(out)
+lanes, waves, paths = o[:64], o[64:128], o[128:136]
+
+
+def show(name, h):
+    tot = sum(h)
+    mean = sum((i * 4 + 2) * c for i, c in enumerate(h)) / max(tot, 1)
+    print(f"{name}: n={tot} mean rounds ~{mean:.1f}")
+    acc = 0
+    for i, c in enumerate(h):
+        acc += c
+        if c:
+            print(f"   {i * 4:>3}-{i * 4 + 3:<3} {100.0 * c / tot:6.2f}%  cum {100.0 * acc / tot:6.2f}%")
+
+
+show("lanes (complete gathers)", lanes)
+show("wavefronts (max over lanes)", waves)
+names = ["pop level", "root pick", "new leaf", "leaf claim/collision", "interior (expand)", "allocation steps",
+         "rounds spent only allocating", "finish at pick"]
+tot = sum(paths[:5]) + paths[6] + paths[7]
+print("lane-rounds by path:")
+for n, c in zip(names, paths):
+    print(f"   {n:<30} {c:>14}  {100.0 * c / max(tot, 1):6.2f}% of lane-rounds")
+print("steps", st.steps, "device_secs", st.device_secs)

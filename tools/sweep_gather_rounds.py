@@ -1,5 +1,5 @@
 """Sweep the gather round limit (AR_GATHER_ROUNDS) on the bench workload, one process, arena kept
-between runs. Usage: python tools/sweep_gather_rounds.py GAMES R1[:LANES[:ALLOC_PER_ROUND]] ... ...   (0 = no limit)"""
+between runs. Usage: python tools/sweep_gather_rounds.py GAMES[/RESIDENT] R1[:LANES[:ALLOC_PER_ROUND]] ... ...   (0 = no limit)"""
 import os
 import sys
 import time
@@ -13,7 +13,9 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 from alpharat_amd.sampling import rust_self_play  # noqa: E402
 
-games = int(sys.argv[1])
+games, _, conc = sys.argv[1].partition("/")
+games = int(games)
+conc = int(conc or games)
 blob = bench.make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet")
 for r in sys.argv[2:]:
     r, _, rest = r.partition(":")
@@ -23,7 +25,7 @@ for r in sys.argv[2:]:
     os.environ["AR_ALLOC_PER_ROUND"] = apr or "2"
     t0 = time.perf_counter()
     st = rust_self_play(**bench.GAME, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
-                        weights_path=str(blob), seed=0, first_game_index=0, concurrent_games=games, **bench.SEARCH)
+                        weights_path=str(blob), seed=0, first_game_index=0, concurrent_games=conc, **bench.SEARCH)
     dt = time.perf_counter() - t0
     print(f"rounds={r:>4} lanes={lanes or 64:>2} alloc/round={apr or 2:>2} wall={dt:7.2f}s device={st.device_secs:7.2f}s steps={st.steps} "
           f"sims/s={st.total_simulations / dt / 1e6:7.1f}M games/s={st.total_games / dt:7.1f} "
