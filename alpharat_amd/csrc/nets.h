@@ -171,35 +171,141 @@ __device__ inline void dense_acc(const float* __restrict__ wt, int K, int H, int
 // Operand lanes: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31];
 // result register v of lane l is out[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31].
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// one pass over K for two column tiles; weights run eight k-steps ahead of the MFMAs in a register ring
+__device__ inline void mfma_tile_pair(const float* ap, const float* bp0, const float* bp1, int K, int H, f32x16& c0,
+                                      f32x16& c1) {
+    float wa[8], wb[8], na[8], nb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wa[j] = 2 * j < K ? bp0[(size_t)(2 * j) * H] : 0.0f;
+        wb[j] = 2 * j < K ? bp1[(size_t)(2 * j) * H] : 0.0f;
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const bool more = k0 + 16 < K;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + 16 + 2 * j;
+                na[j] = k < K ? bp0[(size_t)k * H] : 0.0f;
+                nb[j] = k < K ? bp1[(size_t)k * H] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + 2 * j < K) {  // K is even and wave-uniform
+                const float a = ap[k0 + 2 * j];
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wa[j] = na[j];
+            wb[j] = nb[j];
+        }
+    }
+}
+// `out` may be `act` itself when every wavefront has at most one tile pair (H <= 64 * waves): the block
+// then synchronises between the last read of `act` and the first write. All threads must call this.
 __device__ inline void dense_mfma32_relu(const float* __restrict__ wt, const float* __restrict__ bias, int K, int H,
                                          const float* act, int ld, float* out, int tid, int n_threads) {
     const int wave = tid >> 6, n_waves = n_threads >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const float* ap = act + (size_t)r * ld + h;
-    for (int n0 = wave * 64; n0 < H; n0 += n_waves * 64) {
+    const bool in_place = out == act;
+    for (int n0 = wave * 64; n0 < H || in_place; n0 += n_waves * 64) {
+        const bool has = n0 < H;
         const bool two = n0 + 32 < H;  // wave-uniform
-        const float* bp0 = wt + (size_t)h * H + n0 + r;
-        const float* bp1 = bp0 + (two ? 32 : 0);
         f32x16 c0, c1;
-        const float b0 = bias[n0 + r], b1 = bias[n0 + (two ? 32 : 0) + r];
+        if (has) {
+            const float* bp0 = wt + (size_t)h * H + n0 + r;
+            const float* bp1 = bp0 + (two ? 32 : 0);
+            const float b0 = bias[n0 + r], b1 = bias[n0 + (two ? 32 : 0) + r];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            c0[v] = b0;
-            c1[v] = b1;
+            for (int v = 0; v < 16; ++v) {
+                c0[v] = b0;
+                c1[v] = b1;
+            }
+            mfma_tile_pair(ap, bp0, bp1, K, H, c0, c1);
         }
-#pragma unroll 8
-        for (int k = 0; k < K; k += 2) {
-            const float a = ap[k];
-            const float w0 = bp0[(size_t)k * H], w1 = bp1[(size_t)k * H];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, c1, 0, 0, 0);
-        }
+        if (in_place) __syncthreads();
+        if (has) {
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-            out[(size_t)i * ld + n0 + r] = fmaxf(c0[v], 0.0f);
-            if (two) out[(size_t)i * ld + n0 + 32 + r] = fmaxf(c1[v], 0.0f);
+            for (int v = 0; v < 16; ++v) {
+                const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+                out[(size_t)i * ld + n0 + r] = fmaxf(c0[v], 0.0f);
+                if (two) out[(size_t)i * ld + n0 + 32 + r] = fmaxf(c1[v], 0.0f);
+            }
         }
+        if (in_place) break;
     }
+}
+
+// Head rows for a 32-leaf tile on v_mfma_f32_16x16x4_f32: out[32][n_out <= 16] = bias + act[32][K] x w[n_out][K]^T,
+// wavefronts 0 and 1 take leaves 0-15 and 16-31. Operand lanes: A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15]; result register v of lane l is out[4 (l >> 4) + v][l & 15].
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ inline void heads_mfma16(const float* __restrict__ w, const float* __restrict__ bias, int n_out, int K,
+                                    const float* act, int ld, float* out, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
+    if (wave >= 2) return;
+    const bool col = r < n_out;
+    const float* ap = act + (size_t)(wave * 16 + r) * ld + q;
+    const float* bp = w + (size_t)(col ? r : 0) * K + q;
+    const float b = col ? bias[r] : 0.0f;
+    f32x4 c = {b, b, b, b};
+#pragma unroll 8
+    for (int k = 0; k < K; k += 4) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k], col ? bp[k] : 0.0f, c, 0, 0, 0);
+    if (col)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) out[(wave * 16 + 4 * q + v) * n_out + r] = c[v];
+}
+
+// 32 columns of one weight row, as eight 16-byte loads
+__device__ inline void row_load(float4* acc, const float* __restrict__ row) {
+    const float4* p = (const float4*)row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = p[j];
+}
+__device__ inline void row_acc(float4* acc, const float4* t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j].x += t[j].x;
+        acc[j].y += t[j].y;
+        acc[j].z += t[j].z;
+        acc[j].w += t[j].w;
+    }
+}
+__device__ inline void row_add(float4* acc, const float* __restrict__ row) {
+    const float4* p = (const float4*)row;
+    float4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = p[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j].x += t[j].x;
+        acc[j].y += t[j].y;
+        acc[j].z += t[j].z;
+        acc[j].w += t[j].w;
+    }
+}
+__device__ inline void row_fma(float4* acc, float s, const float* __restrict__ row) {
+    const float4* p = (const float4*)row;
+    float4 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = p[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j].x = fmaf(s, t[j].x, acc[j].x);
+        acc[j].y = fmaf(s, t[j].y, acc[j].y);
+        acc[j].z = fmaf(s, t[j].z, acc[j].z);
+        acc[j].w = fmaf(s, t[j].w, acc[j].w);
+    }
+}
+
+// the MLP kernel keeps one activation buffer when a wavefront's accumulators hold its share of a layer
+__host__ __device__ inline bool mlp_in_place(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
+__host__ __device__ inline size_t mlp_smem_bytes(int H) {
+    return (size_t)(mlp_in_place(H) ? 1 : 2) * TILE_MLP * (H + 4) * 4;
 }
 
 __device__ inline void softmax5(const float* l, float* p) {
@@ -239,10 +345,13 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
     constexpr int L = TILE_MLP;
     extern __shared__ float smem[];
     const int H = net.H, hw = net.hw, ld = H + 4;
-    float* a1 = smem;                    // [L][ld]
-    float* a2 = smem + (size_t)L * ld;   // [L][ld]
+    float* a1 = smem;  // [L][ld]
+    // second-layer output: written over a1 when the MFMA path holds a whole layer in accumulators
+    // (mlp_smem_bytes sizes the allocation to match), which halves the LDS a block needs
+    float* a2 = mlp_in_place(H) ? a1 : smem + (size_t)L * ld;
     __shared__ LeafFeat feat[L];
     __shared__ unsigned long long cheese[L][4];
+    __shared__ float hl[L * 12];
     const uint32_t n = qcount ? *qcount : n_fixed;
     const uint32_t base = blockIdx.x * L;
     if (base >= n) return;
@@ -260,28 +369,68 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
     const float* w1p2 = net.w1t + (size_t)(hw * 5) * H;
     const float* w1ch = net.w1t + (size_t)(hw * 6) * H;
     const float* w1sc = net.w1t + (size_t)(hw * 7) * H;
-    for (int nn = tid; nn < H; nn += NTHREADS) {
-        float ws[6];
-        for (int s = 0; s < 6; ++s) ws[s] = w1sc[(size_t)s * H + nn];
-        for (int l = 0; l < L; ++l) {
+    const bool wide = (H & 31) == 0;  // block-uniform: the paths that work on 32-column pieces
+    if (wide) {
+        // first layer: the observation is one-hot except six scalars, so a leaf's pre-activation is a sum
+        // of weight rows (maze constant, p1 cell, p2 cell, one row per cheese, in that order) plus six
+        // scaled rows. One thread sums 32 columns of one leaf: every row is eight independent 16-byte
+        // loads, so the row fetches overlap instead of queueing behind each other.
+        const int T = H >> 5;
+        for (int item = tid; item < L * T; item += NTHREADS) {
+            const int l = item / T, n0 = (item - l * T) << 5;
             const LeafFeat& f = feat[l];
-            float acc = net.cmaze[(size_t)f.maze_id * H + nn];
-            acc += w1p1[(size_t)f.p1 * H + nn];
-            acc += w1p2[(size_t)f.p2 * H + nn];
+            float4 acc[8], t[8], u[8];
+            row_load(acc, net.cmaze + (size_t)f.maze_id * H + n0);
+            row_load(t, w1p1 + (size_t)f.p1 * H + n0);
+            row_load(u, w1p2 + (size_t)f.p2 * H + n0);
+            row_acc(acc, t);
+            // cheese rows, each fetched while the previous one is added
+            bool have = false;
             for (int wd = 0; wd < 4; ++wd) {
                 unsigned long long m = cheese[l][wd];
                 while (m) {
                     const int c = __ffsll((long long)m) - 1 + 64 * wd;
                     m &= m - 1;
-                    acc += w1ch[(size_t)c * H + nn];
+                    row_load(t, w1ch + (size_t)c * H + n0);
+                    row_acc(acc, u);  // the row fetched one step earlier (p2 the first time)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) u[j] = t[j];
+                    have = true;
                 }
             }
-            for (int s = 0; s < 6; ++s) acc = fmaf(f.sc[s], ws[s], acc);
-            a1[(size_t)l * ld + nn] = fmaxf(acc, 0.0f);
+            (void)have;
+            row_acc(acc, u);
+            for (int s = 0; s < 6; ++s) row_fma(acc, f.sc[s], w1sc + (size_t)s * H + n0);
+            float4* dst = (float4*)(a1 + (size_t)l * ld + n0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                dst[j] = make_float4(fmaxf(acc[j].x, 0.0f), fmaxf(acc[j].y, 0.0f), fmaxf(acc[j].z, 0.0f),
+                                     fmaxf(acc[j].w, 0.0f));
+        }
+    } else {
+        for (int nn = tid; nn < H; nn += NTHREADS) {
+            float ws[6];
+            for (int s = 0; s < 6; ++s) ws[s] = w1sc[(size_t)s * H + nn];
+            for (int l = 0; l < L; ++l) {
+                const LeafFeat& f = feat[l];
+                float acc = net.cmaze[(size_t)f.maze_id * H + nn];
+                acc += w1p1[(size_t)f.p1 * H + nn];
+                acc += w1p2[(size_t)f.p2 * H + nn];
+                for (int wd = 0; wd < 4; ++wd) {
+                    unsigned long long m = cheese[l][wd];
+                    while (m) {
+                        const int c = __ffsll((long long)m) - 1 + 64 * wd;
+                        m &= m - 1;
+                        acc += w1ch[(size_t)c * H + nn];
+                    }
+                }
+                for (int s = 0; s < 6; ++s) acc = fmaf(f.sc[s], ws[s], acc);
+                a1[(size_t)l * ld + nn] = fmaxf(acc, 0.0f);
+            }
         }
     }
     __syncthreads();
-    if ((H & 31) == 0 && (H & 1) == 0) {
+    if (wide) {
         static_assert(L == 32, "the MFMA tile is 32 leaves");
         dense_mfma32_relu(net.w2t, net.b2, H, H, a1, ld, a2, tid, NTHREADS);
     } else {
@@ -296,13 +445,16 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
     }
     __syncthreads();
     // heads: 12 dot products per leaf
-    float* hl = a1;  // reuse: [L][12]
-    for (int idx = tid; idx < L * 12; idx += NTHREADS) {
-        const int l = idx / 12, o = idx % 12;
-        const float* w = net.wh + (size_t)o * H;
-        float acc = net.bh[o];
-        for (int k = 0; k < H; ++k) acc = fmaf(w[k], a2[(size_t)l * ld + k], acc);
-        hl[l * 12 + o] = acc;
+    if (wide) {
+        heads_mfma16(net.wh, net.bh, 12, H, a2, ld, hl, tid);
+    } else {
+        for (int idx = tid; idx < L * 12; idx += NTHREADS) {
+            const int l = idx / 12, o = idx % 12;
+            const float* w = net.wh + (size_t)o * H;
+            float acc = net.bh[o];
+            for (int k = 0; k < H; ++k) acc = fmaf(w[k], a2[(size_t)l * ld + k], acc);
+            hl[l * 12 + o] = acc;
+        }
     }
     __syncthreads();
     if (tid < cnt) {
@@ -525,7 +677,7 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         d.bh = net->upload(bh, ok);
         d.n_head = 12;
         d.Kh = d.H;
-        net->smem = (size_t)2 * TILE_MLP * (d.H + 4) * 4;
+        net->smem = mlp_smem_bytes(d.H);
     } else if (b.arch == ARCH_SYMMETRIC) {
         if (!fold_linear(b, "shared_encoder.0", "shared_encoder.1", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
         if ((int)in != d.hw * 5 + 1) return nets_fail(AR_E_BACKEND, "SymmetricMLP input width does not match the board size");
