@@ -155,6 +155,25 @@ __global__ void k_pool_merge(ArenaPool P) {
     }
 }
 
+// Slot ownership across the two streams of a group. The tree walks (k_gather, k_backup) own a slot
+// while it is ACTIVE; k_advance, on the side stream, owns it from the backup that ended a move (or the
+// gather that stalled) until the compaction is done. No kernel may take over a slot from a kernel that
+// is still running -- only a kernel boundary orders the writes (and writes back / invalidates the
+// per-XCD L2s), and in-kernel agent-scope fences cost a full L2 write-back each. So every hand-off
+// status carries the parity of the step that wrote it, and a kernel only accepts the parity whose
+// writer the stream order has already completed:
+//   backup(t) / gather(t) write ADVANCE / STALL tagged t&1  -> accepted by advance(t) only (launched after
+//                                                             backup(t); advance(t-1) may still be running
+//                                                             next to backup(t) and ignores this parity);
+//   advance(t) writes READY tagged t&1                       -> accepted by gather(t+2), which waits for
+//                                                             advance(t)'s event; gather(t+1) ignores it.
+// Without the side stream everything runs in stream order with phase 0 and READY = ACTIVE.
+enum { SLOT_STALL_B = 6, SLOT_ADVANCE_B = 7, SLOT_READY_A = 8, SLOT_READY_B = 9 };
+__device__ inline uint32_t tag_status(uint32_t st, uint32_t phase) {
+    if (phase == 0) return st;
+    return st == SLOT_STALL ? (uint32_t)SLOT_STALL_B : st == SLOT_ADVANCE ? (uint32_t)SLOT_ADVANCE_B : st;
+}
+
 template <int NW>
 __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, Bases B, SearchCfg cfg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -199,13 +218,18 @@ __global__ void __launch_bounds__(64) k_step_uniform(Slot<NW>* slots, uint32_t n
 template <int NW>
 __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t max_rounds,
-                                               uint32_t lanes, uint32_t first) {
+                                               uint32_t lanes, uint32_t first, uint32_t phase,
+                                               uint32_t accept_ready) {
     // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64)
     if (threadIdx.x >= lanes) return;
     const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
-    if (slots[i].status != SLOT_ACTIVE) return;
+    {
+        const uint32_t st = slots[i].status;
+        if (st != SLOT_ACTIVE && st != accept_ready) return;
+    }
     Slot<NW> s = slots[i];
+    s.status = SLOT_ACTIVE;
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
     // a batch that was already gathered and still waits for its backup is left alone
     const int got = s.batch_active ? GATHER_PENDING : gather_machine_limited(s, m, cfg, EVAL_STORE, max_rounds);
@@ -220,13 +244,14 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
             queue[base + j] = r;
         }
     }
+    s.status = tag_status(s.status, phase);
     slots[i] = s;
 }
 
 template <int NW>
 __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                const ZigTables* zt, const EvalOut* ev_queue, uint32_t lanes,
-                                               uint32_t first) {
+                                               uint32_t first, uint32_t phase) {
     if (threadIdx.x >= lanes) return;
     const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
@@ -235,6 +260,7 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
     const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : m.ev_local;
     if (backup_machine(s, m, cfg, ev, zt)) finish_move(s, m, cfg);
+    s.status = tag_status(s.status, phase);
     slots[i] = s;
 }
 
@@ -249,16 +275,16 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
 // is retried here on every launch: its nodes are copied unchanged into a bigger block.
 template <int NW>
 __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slots, Bases B, SearchCfg cfg,
-                                                uint32_t first_slot) {
+                                                uint32_t first_slot, uint32_t phase, uint32_t ready_status) {
     const uint32_t slot = first_slot + blockIdx.x;
     if (slot >= n_slots) return;
     const uint32_t status = slots[slot].status;
-    if (status != SLOT_ADVANCE && status != SLOT_STALL) return;
+    if (status != tag_status(SLOT_ADVANCE, phase) && status != tag_status(SLOT_STALL, phase)) return;
     const uint32_t lane = threadIdx.x;
     Slot<NW> s = slots[slot];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
 
-    if (status == SLOT_STALL) {
+    if (status == tag_status(SLOT_STALL, phase)) {
         const int want = pool_class_for(B, s.need_nodes > s.cap + 1 ? s.need_nodes : s.cap + 1);
         int cls = POOL_CLASSES;
         uint32_t idx = NIL;
@@ -279,7 +305,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         for (uint32_t w = lane; w < s.hi * (uint32_t)(sizeof(NodeKids) / 16); w += 64) dk[w] = sk[w];
         if (lane == 0) {
             leave_arena(s, d, B);
-            d.status = SLOT_ACTIVE;
+            d.status = ready_status;
             slots[slot] = d;
         }
         return;
@@ -292,7 +318,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
             slot_at_home(d, B, slot);
             leave_arena(s, d, B);
             make_root(d, resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze));
-            d.status = SLOT_ACTIVE;
+            d.status = ready_status;
             slots[slot] = d;
         }
         return;
@@ -391,7 +417,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         d.root = 0;
         d.hi = cnt;
         d.node_count = cnt;
-        d.status = SLOT_ACTIVE;
+        d.status = ready_status;
         slots[slot] = d;
     }
 }
@@ -420,8 +446,9 @@ __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts
     if (slots[i].error) atomicAdd(&counts[3], 1u);
     if (slots[i].release_grown) release_list[atomicAdd(&counts[4], 1u)] = i;
     if (st == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
-    else if (st == SLOT_STALL) stall_list[atomicAdd(&counts[1], 1u)] = i;
-    else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE) atomicAdd(&counts[2], 1u);
+    else if (st == SLOT_STALL || st == SLOT_STALL_B) stall_list[atomicAdd(&counts[1], 1u)] = i;
+    else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE || st == SLOT_ADVANCE_B || st == SLOT_READY_A || st == SLOT_READY_B)
+        atomicAdd(&counts[2], 1u);
 }
 
 // one block per finished game: header by thread 0, position records copied by the whole block
@@ -833,7 +860,15 @@ struct Engine {
                 hipStreamSynchronize(g.stream);
                 hipStreamDestroy(g.stream);
             }
+            if (g.adv_stream) {
+                hipStreamSynchronize(g.adv_stream);
+                hipStreamDestroy(g.adv_stream);
+            }
             if (g.done) hipEventDestroy(g.done);
+            if (g.backed_up) hipEventDestroy(g.backed_up);
+            if (g.adv_ev[0]) hipEventDestroy(g.adv_ev[0]);
+            if (g.adv_ev[1]) hipEventDestroy(g.adv_ev[1]);
+            if (g.adv_done) hipEventDestroy(g.adv_done);
         }
         for (void* p : slot_grown)
             if (p) hipFree(p);
@@ -971,11 +1006,16 @@ struct Engine {
     // Games are split into `n_groups` contiguous slot ranges, each with its own stream and evaluator
     // queue. The groups run the same gather -> evaluate -> backup -> advance sequence independently, so
     // the compute-bound network kernel of one group overlaps the latency-bound tree walks of the others.
+    // Tree reuse (k_advance) runs on a side stream per group: its duration is that of the one slowest
+    // compaction, and the games it works on sit out the next step anyway, so the next gather does not
+    // wait for it (ownership of a slot passes through its status word, see tag_status).
     struct Group {
-        hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
+        hipStream_t stream = nullptr, adv_stream = nullptr;
+        hipEvent_t done = nullptr, backed_up = nullptr, adv_done = nullptr, adv_ev[2] = {nullptr, nullptr};
         uint32_t first = 0, end = 0;  // slots [first, end)
+        uint64_t step = 0;
     };
+    bool overlap_advance = true;
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
         if (n < 1) n = 1;
@@ -990,35 +1030,58 @@ struct Engine {
             } else {
                 groups[g].stream = stream;
             }
+            if (overlap_advance) {
+                HIP_TRY(hipStreamCreateWithFlags(&groups[g].adv_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&groups[g].backed_up, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&groups[g].adv_done, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&groups[g].adv_ev[0], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&groups[g].adv_ev[1], hipEventDisableTiming));
+            }
         }
         return AR_OK;
     }
-    int group_step(const Group& g) {
+    int group_step(Group& g) {
         const uint32_t n = g.end - g.first, gi = (uint32_t)(&g - groups.data());
+        const bool side = g.adv_stream != nullptr;
+        const uint32_t phase = side ? (uint32_t)(g.step & 1) : 0u;
+        const uint32_t ready = side ? (uint32_t)SLOT_READY_A + phase : (uint32_t)SLOT_ACTIVE;
+        if (side) HIP_TRY(hipStreamWaitEvent(g.stream, g.adv_ev[phase], 0));  // advance(step - 2) is complete
         LeafReq<NW>* q = queue.p + (size_t)g.first * cfg.batch_size;
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
         hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                           qc, gather_rounds, lanes, g.first);
+                           qc, gather_rounds, lanes, g.first, phase, ready);
         if (int rc = net_forward_queue<NW>(net, q, qc, (uint32_t)((size_t)n * cfg.batch_size), slots.p, maze.p, ev, g.stream))
             return rc;
         hipLaunchKernelGGL(k_backup<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(),
-                           zig.p, ev, lanes, g.first);
-        hipLaunchKernelGGL(k_advance<NW>, dim3(n), dim3(64), 0, g.stream, slots.p, g.end, bases(), cfg, g.first);
+                           zig.p, ev, lanes, g.first, phase);
+        if (side) {
+            HIP_TRY(hipEventRecord(g.backed_up, g.stream));
+            HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
+            hipLaunchKernelGGL(k_advance<NW>, dim3(n), dim3(64), 0, g.adv_stream, slots.p, g.end, bases(), cfg, g.first,
+                               phase, ready);
+            HIP_TRY(hipEventRecord(g.adv_ev[phase], g.adv_stream));
+        } else {
+            hipLaunchKernelGGL(k_advance<NW>, dim3(n), dim3(64), 0, g.stream, slots.p, g.end, bases(), cfg, g.first, 0u,
+                               (uint32_t)SLOT_ACTIVE);
+        }
+        g.step += 1;
         return AR_OK;
     }
 
     void launch_gather(bool to_queue) {
         hipLaunchKernelGGL(k_gather<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
                            to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr,
-                           gather_rounds, lanes, 0u);
+                           gather_rounds, lanes, 0u, 0u, (uint32_t)SLOT_ACTIVE);
     }
     void launch_backup(bool from_queue) {
         hipLaunchKernelGGL(k_backup<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
-                           zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes, 0u);
+                           zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes, 0u, 0u);
     }
-    void launch_advance() { hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg, 0u); }
+    void launch_advance() {
+        hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg, 0u, 0u, (uint32_t)SLOT_ACTIVE);
+    }
     void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
 
     // `n_launch` rounds of {`iters` simulate_batch per game, then tree reuse for the games that moved},
@@ -1039,16 +1102,23 @@ struct Engine {
             if (groups.empty())
                 if (int rc = make_groups(1)) return rc;
             const bool multi = groups.size() > 1;
-            if (multi)
-                for (const Group& g : groups) HIP_TRY(hipStreamWaitEvent(g.stream, ev0, 0));
+            for (const Group& g : groups) {
+                if (multi) HIP_TRY(hipStreamWaitEvent(g.stream, ev0, 0));
+                if (g.adv_stream) HIP_TRY(hipStreamWaitEvent(g.adv_stream, ev0, 0));
+            }
             for (int k = 0; k < n_launch * iters; ++k)
-                for (const Group& g : groups)
+                for (Group& g : groups)
                     if (int rc = group_step(g)) return rc;
-            if (multi)
-                for (const Group& g : groups) {
+            for (const Group& g : groups) {
+                if (multi) {
                     HIP_TRY(hipEventRecord(g.done, g.stream));
                     HIP_TRY(hipStreamWaitEvent(stream, g.done, 0));
                 }
+                if (g.adv_stream) {  // the host's scan sees every slot at rest
+                    HIP_TRY(hipEventRecord(g.adv_done, g.adv_stream));
+                    HIP_TRY(hipStreamWaitEvent(stream, g.adv_done, 0));
+                }
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));
@@ -1413,9 +1483,10 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
     {
         // groups of games pipelined against each other (Engine::group_step); AR_GROUPS overrides
-        uint32_t ng = (net != nullptr && S >= 4096) ? 4u : 1u;  // small runs: nothing to overlap
+        uint32_t ng = 1;  // measured: more groups do not pay
         if (const char* e = getenv("AR_GROUPS"))
             if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
+        if (getenv("AR_NO_ADVANCE_OVERLAP")) eng.overlap_advance = false;
         if (int rc = eng.make_groups(ng)) return rc;
     }
     if (const char* e = getenv("AR_LANES_PER_WAVE"))

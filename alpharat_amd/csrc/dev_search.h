@@ -115,8 +115,9 @@ struct PosRec {  // selfplay.rs:80-102 PositionRecord
     uint8_t pad[6];
 };
 
+// (128-byte aligned: neighbouring slots can be owned by kernels on different streams and XCDs)
 template <int NW>
-struct Slot {
+struct alignas(128) Slot {
     Board board;
     State<NW> st;
     Rng rng;

@@ -92,8 +92,9 @@ def test_selfplay_with_device_net_runs_and_is_consistent():
 
 
 def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
-    """Groups of games pipelined on separate streams, the gather round limit, the allocation steps per
-    round and the lanes per wavefront only change when work happens, never what a game computes."""
+    """Groups of games pipelined on separate streams, tree reuse on a side stream, the gather round limit,
+    the allocation steps per round and the lanes per wavefront only change when work happens, never what
+    a game computes."""
     from alpharat_amd.sampling import rust_self_play
 
     def run(**env):
@@ -109,7 +110,7 @@ def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
 
     base = run(AR_GROUPS=1)
     for env in (dict(AR_GROUPS=3), dict(AR_GROUPS=2, AR_GATHER_ROUNDS=5), dict(AR_ALLOC_PER_ROUND=1, AR_LANES_PER_WAVE=16),
-                dict(AR_GROUPS=4, AR_ALLOC_PER_ROUND=7, AR_GATHER_ROUNDS=11)):
+                dict(AR_GROUPS=4, AR_ALLOC_PER_ROUND=7, AR_GATHER_ROUNDS=11), dict(AR_NO_ADVANCE_OVERLAP=1)):
         other = run(**env)
         assert sorted(other) == sorted(base)
         for i, g in base.items():
