@@ -533,6 +533,7 @@ struct GatherLane {
     State<NW> work;        // position at the current node
     uint32_t alloc_left;   // visits of the current node still to allocate (0: not in an allocation)
     HalfAlloc h1, h2;      // allocation state of the current node
+    uint32_t kid[25];      // child table of the current node, loaded together with its record
 };
 
 // Starts one simulate_batch. Returns false when the arena cannot take a full batch (the slot
@@ -566,6 +567,7 @@ AR_HD bool gather_begin(GatherLane<NW>& g, Slot<NW>& s, const SearchCfg& cfg, in
     g.eval_mode = eval_mode;
     g.work = s.st;
     g.alloc_left = 0;
+    for (int j = 0; j < 25; ++j) g.kid[j] = NIL;
     return true;
 }
 
@@ -606,6 +608,8 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
             g.omap1 = L.omap[1];
             for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
             g.work = L.saved;
+            const NodeKids& K = m.kids[L.node];
+            for (int j = 0; j < 25; ++j) g.kid[j] = K.c[j];
         } else {
             uint32_t rec = NIL;      // node whose record is inspected
             uint32_t visits_in = 0;  // visits routed to it (pick budget or k)
@@ -641,7 +645,10 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const uint32_t o1 = idx / 5, o2 = idx % 5;
                 float r1, r2;
                 st_step(s.board, m.cost, g.work, outcome_action(g.omap0, o1), outcome_action(g.omap1, o2), r1, r2);
-                const uint32_t child = m.kids[g.node].c[idx];
+                // the child id comes from the table loaded with the parent's record: no dependent load here
+                uint32_t child = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 25; ++j) child |= (j == idx) ? g.kid[j] : 0u;
                 if (child == NIL) {
                     // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
                     AR_COUNT(130);
@@ -678,6 +685,10 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const NodeH0 a = N.h0;
                 const NodeH1 b = N.h1;
                 const NodeH2 c = N.h2;
+                // its child table rides along in the same round trip (used if the node is expanded)
+                const NodeKids& K = m.kids[rec];
+                uint32_t kid_in[25];
+                for (int j = 0; j < 25; ++j) kid_in[j] = K.c[j];
                 if (a.visits == 0 || c.terminal != 0) {
                     // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
                     AR_COUNT(131);
@@ -719,6 +730,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                     g.omap1 = c.omap[1];
                     g.mask = 0;
                     for (int j = 0; j < 13; ++j) g.vtp[j] = 0;
+                    for (int j = 0; j < 25; ++j) g.kid[j] = kid_in[j];
                     s.nv_gather += 1;
                     g.alloc_left = visits_in;
                 }
