@@ -660,6 +660,7 @@ SearchCfg to_cfg(const ArSearchConfig& c, uint32_t sims, uint32_t batch) {
     s.n_sims = sims;
     s.batch_size = batch;
     s.alloc_per_round = 2;  // measured best on the bench workload; results do not depend on it
+    s.debug_extra_loads = getenv("AR_DEBUG_EXTRA_LOADS") ? (uint32_t)atoi(getenv("AR_DEBUG_EXTRA_LOADS")) : 0u;
     if (const char* e = getenv("AR_ALLOC_PER_ROUND"))
         if (atoi(e) >= 1) s.alloc_per_round = (uint32_t)atoi(e);
     return s;
@@ -1834,6 +1835,13 @@ int ar_debug_gather_hist(unsigned long long* out136) {
     HIP_TRY(hipMemcpyFromSymbol(out136, HIP_SYMBOL(ar::g_gather_hist), sizeof(unsigned long long) * 136));
     unsigned long long z[136] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ar::g_gather_hist), z, sizeof z));
+    return AR_OK;
+}
+int ar_debug_gather_clk(unsigned long long* out128) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out128, HIP_SYMBOL(ar::g_gather_clk), sizeof(unsigned long long) * 128));
+    unsigned long long z[128] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(ar::g_gather_clk), z, sizeof z));
     return AR_OK;
 }
 #endif

@@ -70,6 +70,7 @@ struct SearchCfg {
     float coll_power;
     uint32_t n_sims, batch_size;
     uint32_t alloc_per_round;  // scheduling only: allocation-loop steps one gather round runs (gather_round)
+    uint32_t debug_extra_loads;  // experiment only: re-read every inspected record this many times
 };
 
 enum { SLOT_EMPTY = 0, SLOT_ACTIVE = 1, SLOT_DONE = 2, SLOT_STALL = 3, SLOT_FAILED = 4, SLOT_ADVANCE = 5 };
@@ -438,7 +439,13 @@ __device__ unsigned long long g_round_stats[32];  // [machine*16 + state*2 + {ro
 // [0..63] lanes by rounds/4 of one gather, [64..127] wavefronts by (max rounds)/4, [128..135] lane-rounds by
 // path: pop, pick, new leaf, leaf claim, interior, allocation steps, rounds in allocation only, done-at-pick
 __device__ unsigned long long g_gather_hist[136];
+// wavefront clocks of the gather loop by (max rounds)/4: [b] = sum of clocks, [64 + b] = wavefronts
+__device__ unsigned long long g_gather_clk[128];
+#if defined(AR_STATS_PATHS)  // per-lane path counters: heavy (contended atomics), distorts timings
 #define AR_COUNT(i) atomicAdd(&g_gather_hist[i], 1ULL)
+#else
+#define AR_COUNT(i) ((void)0)
+#endif
 #else
 #define AR_COUNT(i) ((void)0)
 #endif
@@ -453,7 +460,7 @@ AR_HD uint32_t elect_state(uint32_t state, uint32_t n_states, uint32_t done_stat
             best = st;
         }
     }
-#if defined(AR_STATS)
+#if defined(AR_STATS_PATHS)
     if (best != done_state) {
         const int alive = __popcll(__ballot(state != done_state));
         if (__popcll(__ballot(1) & ((1ULL << (threadIdx.x & 63)) - 1ULL)) == 0) {
@@ -592,7 +599,7 @@ enum { PROC_NONE = 0xFFu };
 template <int NW>
 AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     if (g.state == G_DONE) return;
-#if defined(AR_STATS) && defined(__HIPCC__)
+#if defined(AR_STATS_PATHS) && defined(__HIPCC__)
     if (g.alloc_left != 0) AR_COUNT(134);
 #endif
     if (g.alloc_left == 0) {
@@ -685,6 +692,14 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const NodeH0 a = N.h0;
                 const NodeH1 b = N.h1;
                 const NodeH2 c = N.h2;
+#if defined(__HIP_DEVICE_COMPILE__)
+                for (uint32_t x = 0; x < cfg.debug_extra_loads; ++x) {  // (measurement aid, off by default)
+                    const volatile uint4* vp = (const volatile uint4*)&N;
+                    uint32_t sink = 0;
+                    for (int j = 0; j < 16; ++j) sink += vp[j].x;
+                    if (sink == 0x7fffffffu) s.error = 9;
+                }
+#endif
                 // its child table rides along in the same round trip (used if the node is expanded)
                 const NodeKids& K = m.kids[rec];
                 uint32_t kid_in[25];
@@ -795,6 +810,9 @@ AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg&
     if (s.gather_pending) g = *parked;
     else ok = gather_begin(g, s, cfg, eval_mode);
     uint32_t my_rounds = 0;
+#if defined(AR_STATS) && defined(__HIPCC__)
+    const unsigned long long clk0 = wall_clock64();
+#endif
     for (uint32_t r = 0; r < max_rounds; ++r) {
         const uint32_t run = elect_state(g.state, G_DONE, G_DONE);
         if (run == G_DONE) break;
@@ -802,6 +820,14 @@ AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg&
             gather_round(g, s, m, cfg);
             my_rounds += 1;
         }
+#if defined(AR_STATS) && defined(__HIPCC__)
+        // checkpoints: clocks since the loop began after 1, 2, 4, 8, 16, 32, 64, 128 wavefront rounds
+        if (((r + 1) & r) == 0 && r < 128 && (threadIdx.x & 63) == 0) {
+            const int cp = 31 - __clz((int)(r + 1));
+            atomicAdd(&g_gather_clk[112 + cp], wall_clock64() - clk0);
+            atomicAdd(&g_gather_clk[120 + cp], 1ULL);
+        }
+#endif
     }
 #if defined(AR_STATS) && defined(__HIPCC__)
     {
@@ -810,8 +836,15 @@ AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg&
             const uint32_t o = (uint32_t)__shfl_xor((int)wave_max, off, 64);
             wave_max = o > wave_max ? o : wave_max;
         }
+#if defined(AR_STATS_PATHS)
         if (ok) atomicAdd(&g_gather_hist[my_rounds / 4 < 63 ? my_rounds / 4 : 63], 1ULL);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&g_gather_hist[64 + (wave_max / 4 < 63 ? wave_max / 4 : 63)], 1ULL);
+#endif
+        if ((threadIdx.x & 63) == 0) {
+            const uint32_t b = wave_max / 8 < 47 ? wave_max / 8 : 47;  // clk: [0..47] sums, [64..111] counts by rounds/8
+            atomicAdd(&g_gather_hist[64 + (wave_max / 4 < 63 ? wave_max / 4 : 63)], 1ULL);
+            atomicAdd(&g_gather_clk[b], wall_clock64() - clk0);
+            atomicAdd(&g_gather_clk[64 + b], 1ULL);
+        }
     }
 #endif
     (void)my_rounds;

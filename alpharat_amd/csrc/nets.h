@@ -241,13 +241,13 @@ __device__ inline void dense_mfma32_relu(const float* __restrict__ wt, const flo
 }
 
 // Head rows for a 32-leaf tile on v_mfma_f32_16x16x4_f32: out[32][n_out <= 16] = bias + act[32][K] x w[n_out][K]^T,
-// wavefronts 0 and 1 take leaves 0-15 and 16-31. Operand lanes: A[i = lane & 15][k = lane >> 4],
+// wavefront w takes leaves 16w .. 16w+15. Operand lanes: A[i = lane & 15][k = lane >> 4],
 // B[k = lane >> 4][j = lane & 15]; result register v of lane l is out[4 (l >> 4) + v][l & 15].
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ inline void heads_mfma16(const float* __restrict__ w, const float* __restrict__ bias, int n_out, int K,
-                                    const float* act, int ld, float* out, int tid) {
+                                    const float* act, int ld, float* out, int tid, int n_tiles = 2) {
     const int wave = tid >> 6, lane = tid & 63, r = lane & 15, q = lane >> 4;
-    if (wave >= 2) return;
+    if (wave >= n_tiles) return;
     const bool col = r < n_out;
     const float* ap = act + (size_t)(wave * 16 + r) * ld + q;
     const float* bp = w + (size_t)(col ? r : 0) * K + q;
@@ -469,6 +469,174 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
             for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = h[k];
     }
 }
+
+// ---- PyRatMLP, all three layers on the matrix cores (hidden width a multiple of 32, at most 256) ----
+// One block evaluates 32*MT leaves. The first layer is the same k-ordered sum as in k_mlp written as a
+// dense product over the non-maze part of the observation: x = [p1 one-hot | p2 one-hot | cheese mask |
+// six scalars] (K1 = 3 hw + 6), accumulator initialised with the per-maze constant. Products with x = 0
+// add nothing and x = 1 adds the weight row itself, so the chain is the one k_mlp's row sums compute --
+// but the weights stream through once per block (K1 rows) instead of once per leaf (one row per set
+// feature), which is what bounded k_mlp: ~19 KB of L2 reads per leaf against ~2.4 KB here.
+// The operand x is generated in registers from the leaf's cells and cheese mask; nothing is staged.
+template <int MT, class AFn>
+__device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h, AFn a_of, f32x16 (&c)[MT][2]) {
+    const float* bp1 = bp0 + (two ? 32 : 0);
+    float wa[8], wb[8], na[8], nb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 2 * j;
+        wa[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
+        wb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        if (k0 + 16 < K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + 16 + 2 * j;
+                na[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
+                nb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 2 * j;
+            if (k < K) {  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float a = a_of(k, t);
+                    c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c[t][0], 0, 0, 0);
+                    c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c[t][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wa[j] = na[j];
+            wb[j] = nb[j];
+        }
+    }
+}
+
+template <int NW, int MT>
+__global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                       uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                       ar::EvalOut* out, float* logits) {
+    constexpr int L = 32 * MT;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4;
+    float* act = smem;  // [L][ld], both hidden layers in turn
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    __shared__ float hl[L * 12];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
+    f32x16 c[MT][2];
+    if (has) {
+        // first layer
+        int p1[MT], p2[MT];
+        unsigned long long ch[MT][NW];
+        float sc[MT][6];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const LeafFeat& f = feat[32 * t + r];
+            p1[t] = f.p1;
+            p2[t] = f.p2;
+            for (int s6 = 0; s6 < 6; ++s6) sc[t][s6] = f.sc[s6];
+            for (int w = 0; w < NW; ++w) ch[t][w] = cheese[32 * t + r][w];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + n0 + r;
+                c[t][0][v] = cm[0];
+                c[t][1][v] = cm[two ? 32 : 0];
+            }
+        auto x_of = [&](int k, int t) -> float {
+            const int kk = k + h;
+            if (kk < hw) return kk == p1[t] ? 1.0f : 0.0f;
+            if (kk < 2 * hw) return kk - hw == p2[t] ? 1.0f : 0.0f;
+            if (kk < 3 * hw) {
+                const int bit = kk - 2 * hw;
+                unsigned long long word = ch[t][0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) word = (bit >> 6) == w ? ch[t][w] : word;
+                return (word >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
+            }
+            const int s6 = kk - 3 * hw;
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
+            return v;
+        };
+        mfma_pass<MT>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, 3 * hw + 6, H, h, x_of, c);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                act[(size_t)i * ld + n0 + r] = fmaxf(c[t][0][v], 0.0f);
+                if (two) act[(size_t)i * ld + n0 + 32 + r] = fmaxf(c[t][1][v], 0.0f);
+            }
+    }
+    __syncthreads();
+    if (has) {
+        // second layer, result held in the accumulators until every wavefront is done reading `act`
+        const float b0 = net.b2[n0 + r], b1 = net.b2[n0 + (two ? 32 : 0) + r];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                c[t][0][v] = b0;
+                c[t][1][v] = b1;
+            }
+        const float* ap = act + (size_t)r * ld + h;
+        auto a_of = [&](int k, int t) -> float { return ap[(size_t)(32 * t) * ld + k]; };
+        mfma_pass<MT>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_of, c);
+    }
+    __syncthreads();
+    if (has) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                act[(size_t)i * ld + n0 + r] = fmaxf(c[t][0][v], 0.0f);
+                if (two) act[(size_t)i * ld + n0 + 32 + r] = fmaxf(c[t][1][v], 0.0f);
+            }
+    }
+    __syncthreads();
+    heads_mfma16(net.wh, net.bh, 12, H, act, ld, hl, tid, 2 * MT);
+    __syncthreads();
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 5, o.p2);
+        o.v1 = softplusf(hh[10]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = hh[k];
+    }
+}
+__host__ __device__ inline bool mlp_all_mfma(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
+static const int MLP_MFMA_MT = 2;  // 64 leaves per block
 
 // ---- SymmetricMLP -----------------------------------------------------------------------------
 template <int NW>
@@ -820,7 +988,8 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
                       size_t board_stride, ar::EvalOut* out, float* logits, hipStream_t stream) {
     using namespace arnet;
     if (n_max == 0) return AR_OK;
-    const int tile = net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
+    const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
+    const int tile = mlp_mfma ? 32 * MLP_MFMA_MT : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_CNN) {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_cnn<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -828,6 +997,13 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
         hipLaunchKernelGGL(k_cnn<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max, boards,
                            board_stride, net->bound_pool, out, logits);
+    } else if (mlp_mfma) {
+        const size_t smem = (size_t)32 * MLP_MFMA_MT * (net->dev.H + 4) * 4;
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_mlp_mfma<NW, MLP_MFMA_MT>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
+        hipLaunchKernelGGL((k_mlp_mfma<NW, MLP_MFMA_MT>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount,
+                           n_max, boards, board_stride, out, logits);
     } else if (net->dev.arch == ARCH_MLP) {
         if (net->smem > 48 * 1024 &&
             hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) !=

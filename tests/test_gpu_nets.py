@@ -119,3 +119,45 @@ def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
                     np.testing.assert_array_equal(val, other[i][key], err_msg=f"{env} game {i} {key}")
                 else:
                     assert val == other[i][key], (env, i, key)
+
+
+@pytest.mark.parametrize("hidden", [48, 64, 96, 320], ids=lambda h: f"h{h}")
+def test_device_mlp_other_hidden_widths_match_the_oracle_net(hidden, tmp_path):
+    """Hidden widths the golden vectors do not cover take other kernel paths (48: scalar tile loops;
+    64 / 96: matrix-core kernel with idle or single-tile wavefronts; 320: matrix-core second layer with
+    two activation buffers). Seeded random weights, 70 random positions (more than one 64-leaf tile),
+    compared with the oracle's forward pass of the same blob on the device's own observations."""
+    from alpharat_amd.game import PyRat
+    from alpharat_amd.nets import Net, encode
+    from alpharat_amd.weights import write_blob
+
+    rng = np.random.default_rng(hidden)
+    w = h = 7
+    d = w * h * 7 + 6
+    t = {}
+    for name, (o, i) in {"trunk.0": (hidden, d), "trunk.4": (hidden, hidden)}.items():
+        t[f"{name}.weight"] = (rng.standard_normal((o, i)) * np.sqrt(2.0 / i)).astype(np.float32)
+        t[f"{name}.bias"] = (rng.standard_normal(o) * 0.1).astype(np.float32)
+    for bn in ("trunk.1", "trunk.5"):
+        t[f"{bn}.weight"] = (1 + 0.1 * rng.standard_normal(hidden)).astype(np.float32)
+        t[f"{bn}.bias"] = (0.1 * rng.standard_normal(hidden)).astype(np.float32)
+        t[f"{bn}.running_mean"] = (0.1 * rng.standard_normal(hidden)).astype(np.float32)
+        t[f"{bn}.running_var"] = (1 + 0.1 * rng.random(hidden)).astype(np.float32)
+    for name, o in (("policy_p1_head", 5), ("policy_p2_head", 5), ("value_head", 2)):
+        t[f"{name}.weight"] = (rng.standard_normal((o, hidden)) * 0.2).astype(np.float32)
+        t[f"{name}.bias"] = (0.1 * rng.standard_normal(o)).astype(np.float32)
+    blob = write_blob(tmp_path / f"mlp_h{hidden}.arnet", "mlp", w, h, t)
+    games = []
+    for i in range(70):
+        cells = rng.permutation(w * h)
+        cheese = [(int(c % w), int(c // w)) for c in cells[: int(rng.integers(1, 14))]]
+        g = PyRat.create_custom(w, h, cheese=cheese, player1_pos=(int(cells[20] % w), int(cells[20] // w)),
+                                player2_pos=(int(cells[21] % w), int(cells[21] // w)), max_turns=50)
+        for _ in range(int(rng.integers(0, 6))):
+            g.make_move(int(rng.integers(0, 5)), int(rng.integers(0, 5)))
+        games.append(g)
+    obs = encode(games)
+    want = O.Net(blob).forward(obs)
+    got = Net(blob).evaluate(games)
+    for k in ("logits_p1", "logits_p2", "policy_p1", "policy_p2", "value_p1", "value_p2"):
+        np.testing.assert_allclose(got[k], want[k], atol=1e-5, rtol=1e-5, err_msg=f"h{hidden}:{k}")

@@ -14,9 +14,10 @@ from alpharat_amd.sampling import rust_self_play  # noqa: E402
 
 L = _lib.load()
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+resident = int(sys.argv[2]) if len(sys.argv) > 2 else games
 blob = bench.make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet")
 st = rust_self_play(**bench.GAME, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
-                    weights_path=str(blob), seed=0, concurrent_games=games, **bench.SEARCH)
+                    weights_path=str(blob), seed=0, concurrent_games=resident, **bench.SEARCH)
 out = (C.c_ulonglong * 136)()
 L.ar_debug_gather_hist.argtypes = [C.c_void_p]
 L.ar_debug_gather_hist(out)
@@ -43,4 +44,17 @@ tot = sum(paths[:5]) + paths[6] + paths[7]
 print("lane-rounds by path:")
 for n, c in zip(names, paths):
     print(f"   {n:<30} {c:>14}  {100.0 * c / max(tot, 1):6.2f}% of lane-rounds")
+clk = (C.c_ulonglong * 128)()
+L.ar_debug_gather_clk.argtypes = [C.c_void_p]
+L.ar_debug_gather_clk(clk)
+clk = list(clk)
+print("gather loop wall clock (100 MHz ticks -> us) by wavefront max rounds:")
+for b in range(48):
+    if clk[64 + b]:
+        us = clk[b] / clk[64 + b] / 100.0
+        print(f"   rounds {b * 8:>3}-{b * 8 + 7:<3} waves {clk[64 + b]:>9}  mean {us:9.1f} us  per round {us / (b * 8 + 4):6.2f} us")
+print("mean time since the loop began after N wavefront rounds:")
+for cp in range(8):
+    if clk[120 + cp]:
+        print(f"   after {1 << cp:>3} rounds: {clk[112 + cp] / clk[120 + cp] / 100.0:9.1f} us  ({clk[120 + cp]} wavefronts)")
 print("steps", st.steps, "device_secs", st.device_secs)
