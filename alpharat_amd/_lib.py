@@ -78,6 +78,7 @@ class ArSelfPlayStats(C.Structure):
         ("cache_hits", C.c_uint64), ("cache_misses", C.c_uint64),
         ("gather_node_visits", C.c_uint64), ("backup_node_visits", C.c_uint64), ("new_nodes", C.c_uint64),
         ("device_secs", C.c_double), ("steps", C.c_uint64),
+        ("gather_secs", C.c_double), ("gather_launches", C.c_uint64),
     ]
 
 

@@ -873,6 +873,7 @@ struct Engine {
         }
         for (void* p : slot_grown)
             if (p) hipFree(p);
+        for (hipEvent_t e : gather_ev) hipEventDestroy(e);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (stream) hipStreamDestroy(stream);
@@ -1016,6 +1017,11 @@ struct Engine {
         uint32_t first = 0, end = 0;  // slots [first, end)
         uint64_t step = 0;
     };
+    // HIP events around every k_gather launch of group 0 (on the stream it runs on); read back in scan()
+    std::vector<hipEvent_t> gather_ev;
+    size_t gather_ev_used = 0;
+    double gather_ms = 0.0;
+    uint64_t gather_launches = 0;
     bool overlap_advance = true;
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
@@ -1051,8 +1057,21 @@ struct Engine {
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
+        const bool timed_launch = gi == 0;
+        if (timed_launch) {
+            while (gather_ev.size() < gather_ev_used + 2) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(hipEventCreate(&e));
+                gather_ev.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(gather_ev[gather_ev_used], g.stream));
+        }
         hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
                            qc, gather_rounds, lanes, g.first, phase, ready);
+        if (timed_launch) {
+            HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
+            gather_ev_used += 2;
+        }
         if (int rc = net_forward_queue<NW>(net, q, qc, (uint32_t)((size_t)n * cfg.batch_size), slots.p, maze.p, ev, g.stream))
             return rc;
         hipLaunchKernelGGL(k_backup<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(),
@@ -1151,6 +1170,14 @@ struct Engine {
             if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) device_ms += ms;
             timed = false;
         }
+        for (size_t i = 0; i + 1 < gather_ev_used; i += 2) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, gather_ev[i], gather_ev[i + 1]) == hipSuccess) {
+                gather_ms += ms;
+                gather_launches += 1;
+            }
+        }
+        gather_ev_used = 0;
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
         for (int c = 0; c < POOL_CLASSES; ++c)
             if (pool.n[c] && h_counts.p[5 + c] < pool_low[c]) pool_low[c] = h_counts.p[5 + c];
@@ -1620,6 +1647,8 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     if (st.total_games == 0) st.min_turns = 0;
     st.device_secs = eng.device_ms / 1000.0;
     st.steps = eng.steps;
+    st.gather_secs = eng.gather_ms / 1000.0;
+    st.gather_launches = eng.gather_launches;
     if (timing)
         fprintf(stderr,
                 "[ar timing] games=%u resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "

@@ -22,12 +22,13 @@ class SelfPlayStats:
             "total_cheese_collected", "total_cheese_available", "min_turns", "max_turns", "total_nn_evals",
             "total_terminals", "total_collisions", "cache_hits", "cache_misses",
             # extensions: roofline instrumentation
-            "gather_node_visits", "backup_node_visits", "new_nodes", "device_secs", "steps")
+            "gather_node_visits", "backup_node_visits", "new_nodes", "device_secs", "steps", "gather_secs",
+            "gather_launches")
 
     def __init__(self, s: _lib.ArSelfPlayStats | None = None, **kw: Any) -> None:
         for k in self._RAW:
             v = getattr(s, k) if s is not None else kw.get(k, 0)
-            object.__setattr__(self, k, float(v) if k in ("elapsed_secs", "total_cheese_collected", "device_secs") else int(v))
+            object.__setattr__(self, k, float(v) if k in ("elapsed_secs", "total_cheese_collected", "device_secs", "gather_secs") else int(v))
 
     def __setattr__(self, k: str, v: Any) -> None:
         raise AttributeError("SelfPlayStats is read-only")
@@ -76,6 +77,8 @@ class SelfPlayStats:
         kw["elapsed_secs"] = max(self.elapsed_secs, o.elapsed_secs)
         kw["device_secs"] = max(self.device_secs, o.device_secs)
         kw["steps"] = max(self.steps, o.steps)
+        kw["gather_secs"] = max(self.gather_secs, o.gather_secs)
+        kw["gather_launches"] = max(self.gather_launches, o.gather_launches)
         mins = [s.min_turns for s in (self, o) if s.total_games > 0]
         kw["min_turns"] = min(mins) if mins else 0
         kw["max_turns"] = max(self.max_turns, o.max_turns)

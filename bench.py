@@ -31,6 +31,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes of the tree kernels
 B_NODE_VISIT, B_NEW_NODE, B_NN_LEAF = 300, 304, 1444
+B_SELECT_VISIT = 204  # the select half of SURVEY 8d's 300 B node-visit (192 B read + 12 B virtual-loss writes)
+B_LEAF_REQ = 40  # one evaluator request written by the gather: position + slot id
 
 SEARCH = dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83)
 GAME = dict(width=7, height=7, cheese_count=10, max_turns=50)
@@ -146,16 +148,23 @@ def main() -> int:
     sync()
     t0 = time.perf_counter()
     stats = None
+    dev_secs = gather_secs = 0.0
+    dev_steps = gather_launches = 0
     for k in range(args.steps):
         s = one_step(k)
         stats = s if stats is None else stats + s
+        # sequential passes: device times and launch counts add up (SelfPlayStats.__add__ merges parallel shards)
+        dev_secs += s.device_secs
+        dev_steps += s.steps
+        gather_secs += s.gather_secs
+        gather_launches += s.gather_launches
     sync()
     elapsed = time.perf_counter() - t0
 
     tot = dict(sims=stats.total_simulations, games=stats.total_games, nn=stats.total_nn_evals,
                desc=stats.total_nn_evals + stats.total_terminals, positions=stats.total_positions,
                nv=stats.gather_node_visits + stats.backup_node_visits, new=stats.new_nodes)
-    tree_secs, net_secs, dev_steps = stats.device_secs, 0.0, stats.steps
+    tree_secs = dev_secs
     if dist is not None:
         import torch
 
@@ -168,11 +177,25 @@ def main() -> int:
     if rank != 0:
         return 0
 
-    # roofline of the dominant kernels (tree walk): algorithmic bytes / device time in the step kernels,
-    # both from rank 0's own counters and HIP-event timings
-    alg_bytes = (B_NODE_VISIT * (stats.gather_node_visits + stats.backup_node_visits) + B_NEW_NODE * stats.new_nodes
-                 + (B_NN_LEAF * stats.total_nn_evals if args.evaluator == "mlp" else 0))
-    achieved = alg_bytes / max(tree_secs, 1e-9) / 1e9
+    # roofline of the dominant kernel, k_gather (rank 0's own counters): algorithmic bytes of one launch =
+    # SURVEY.md 8d's per-unit figures x the units one launch processes (node records inspected on the way
+    # down, nodes created, leaf positions handed to the evaluator), divided by the launch's duration from
+    # HIP events recorded on the kernel's own stream around every launch.
+    gather_bytes = (B_SELECT_VISIT * stats.gather_node_visits + B_NEW_NODE * stats.new_nodes
+                    + (B_LEAF_REQ * stats.total_nn_evals if args.evaluator == "mlp" else 0))
+    launches = max(gather_launches, 1)
+    if args.evaluator == "mlp" and gather_secs > 0:
+        avg_launch_s = gather_secs / launches
+        achieved = gather_bytes / launches / avg_launch_s / 1e9
+        kernel = "k_gather"
+    else:  # SmartUniform: one fused step kernel, timed as a whole
+        gather_bytes += (B_NODE_VISIT - B_SELECT_VISIT) * stats.backup_node_visits
+        launches = max(dev_steps, 1)
+        avg_launch_s = tree_secs / launches
+        achieved = gather_bytes / launches / max(avg_launch_s, 1e-12) / 1e9
+        kernel = "k_step_uniform (+ k_advance)"
+    step_bytes = (B_NODE_VISIT * (stats.gather_node_visits + stats.backup_node_visits) + B_NEW_NODE * stats.new_nodes
+                  + (B_NN_LEAF * stats.total_nn_evals if args.evaluator == "mlp" else 0))
     out = {
         "metric": "MCTS simulations/sec, self-play 7x7 PyRat at the tuned 1897-sim config",
         "value": tot["sims"] / elapsed,
@@ -198,10 +221,11 @@ def main() -> int:
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "tree step kernels (k_gather + k_backup" + (" + evaluator" if args.evaluator == "mlp" else "") + ")",
-            "device_secs": tree_secs, "batch_steps": dev_steps,
-            "avg_step_ms": tree_secs / max(dev_steps, 1) * 1e3,
-            "algorithmic_bytes": alg_bytes,
+            "kernel": kernel, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+            "algorithmic_bytes_per_launch": gather_bytes / launches,
+            # the whole step (gather + evaluator + backup, tree reuse overlapped) for reference
+            "step": {"batch_steps": dev_steps, "device_secs": tree_secs, "avg_step_ms": tree_secs / max(dev_steps, 1) * 1e3,
+                     "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / max(tree_secs, 1e-9) / 1e9},
         },
     }
     if not args.no_cpu_baseline:

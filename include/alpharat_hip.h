@@ -166,6 +166,8 @@ typedef struct ArSelfPlayStats {
     uint64_t gather_node_visits, backup_node_visits, new_nodes;
     double device_secs; /* time inside step kernels (HIP events) */
     uint64_t steps;     /* batch steps launched */
+    double gather_secs; /* time inside the gather kernel alone: HIP events around every launch, on its stream */
+    uint64_t gather_launches;
 } ArSelfPlayStats;
 
 /* crates/alpharat-sampling/src/selfplay.rs:343-359: live counters in caller-owned memory, written
