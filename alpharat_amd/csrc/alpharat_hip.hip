@@ -660,7 +660,6 @@ SearchCfg to_cfg(const ArSearchConfig& c, uint32_t sims, uint32_t batch) {
     s.n_sims = sims;
     s.batch_size = batch;
     s.alloc_per_round = 2;  // measured best on the bench workload; results do not depend on it
-    s.debug_extra_loads = getenv("AR_DEBUG_EXTRA_LOADS") ? (uint32_t)atoi(getenv("AR_DEBUG_EXTRA_LOADS")) : 0u;
     if (const char* e = getenv("AR_ALLOC_PER_ROUND"))
         if (atoi(e) >= 1) s.alloc_per_round = (uint32_t)atoi(e);
     return s;

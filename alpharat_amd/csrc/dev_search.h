@@ -70,7 +70,6 @@ struct SearchCfg {
     float coll_power;
     uint32_t n_sims, batch_size;
     uint32_t alloc_per_round;  // scheduling only: allocation-loop steps one gather round runs (gather_round)
-    uint32_t debug_extra_loads;  // experiment only: re-read every inspected record this many times
 };
 
 enum { SLOT_EMPTY = 0, SLOT_ACTIVE = 1, SLOT_DONE = 2, SLOT_STALL = 3, SLOT_FAILED = 4, SLOT_ADVANCE = 5 };
@@ -692,14 +691,6 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const NodeH0 a = N.h0;
                 const NodeH1 b = N.h1;
                 const NodeH2 c = N.h2;
-#if defined(__HIP_DEVICE_COMPILE__)
-                for (uint32_t x = 0; x < cfg.debug_extra_loads; ++x) {  // (measurement aid, off by default)
-                    const volatile uint4* vp = (const volatile uint4*)&N;
-                    uint32_t sink = 0;
-                    for (int j = 0; j < 16; ++j) sink += vp[j].x;
-                    if (sink == 0x7fffffffu) s.error = 9;
-                }
-#endif
                 // its child table rides along in the same round trip (used if the node is expanded)
                 const NodeKids& K = m.kids[rec];
                 uint32_t kid_in[25];

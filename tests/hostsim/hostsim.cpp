@@ -60,7 +60,6 @@ static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
     s.n_sims = n_sims;
     s.batch_size = batch;
     s.alloc_per_round = 2;
-    s.debug_extra_loads = 0;
     return s;
 }
 
