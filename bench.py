@@ -228,7 +228,7 @@ def main() -> int:
                      "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / max(tree_secs, 1e-9) / 1e9},
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(blob, args.evaluator)
     print(json.dumps(out))
     if dist is not None:
