@@ -103,6 +103,12 @@ def main() -> int:
     if world != args.gpus:
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
 
+    if world > 1:
+        # torch first: it ships its own copy of the HIP runtime, and a process can only bring up one --
+        # loaded after torch, libalpharat_hip binds to that copy (tools/probe_torch_hip.py); the other
+        # order leaves whichever runtime initialises second without a device
+        import torch  # noqa: F401
+
     import __graft_entry__ as ge
 
     if rank == 0:
@@ -112,8 +118,13 @@ def main() -> int:
         import torch
         import torch.distributed as dist_mod
 
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl")
+        # rehearsal knobs (one-GPU box): AR_BENCH_BACKEND=gloo AR_BENCH_DEVICE=0 run every rank on the same device
+        backend = os.environ.get("AR_BENCH_BACKEND", "nccl")
+        if "AR_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["AR_BENCH_DEVICE"])
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend)
         dist = dist_mod
         dist.barrier()
     from alpharat_amd.sampling import rust_self_play
@@ -142,7 +153,8 @@ def main() -> int:
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if dist.get_backend() == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     sync()
@@ -168,10 +180,11 @@ def main() -> int:
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], device="cuda")
+        red_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        v = torch.tensor([float(x) for x in tot.values()], dtype=torch.float64, device="cuda")
+        v = torch.tensor([float(x) for x in tot.values()], dtype=torch.float64, device=red_dev)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         tot = dict(zip(tot.keys(), [float(x) for x in v.tolist()]))
     if rank != 0:
