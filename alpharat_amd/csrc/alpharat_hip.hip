@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     const uint32_t first = keep_root & ~63u;
     for (uint32_t base = 0; base < first; base += 64) {  // everything before the kept root is dropped
         const uint32_t i = base + lane;
-        if (i < hi) __hip_atomic_store(&m.fwd[i], NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < hi) __hip_atomic_store(&m.fwd[i], NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     for (uint32_t base = first; base < hi; base += 64) {
         const uint32_t i = base + lane;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
                 p = m.stats[i].h1.parent;
                 if (p == NIL) st = 2;
                 else if (p < base)
-                    st = __hip_atomic_load(&m.fwd[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NIL ? 1u : 2u;
+                    st = __hip_atomic_load(&m.fwd[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != NIL ? 1u : 2u;
                 else st = 0;
             }
         }
@@ -355,11 +355,16 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         const unsigned long long bal = __ballot(keep);
         const uint32_t before = (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
         if (i < hi)
-            __hip_atomic_store(&m.fwd[i], keep ? cnt + before : NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&m.fwd[i], keep ? cnt + before : NIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         cnt += (uint32_t)__popcll(bal);
+        // the next group's lanes read this group's new ids: the stores must have left the wavefront
+        // (one wavefront on one CU: workgroup scope is enough, and an agent-scope fence would write
+        // back the XCD's whole L2 -- 550 times per step)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    __threadfence();  // all new ids are in L2 before any lane reads another lane's
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // destination arena: the smallest that holds the kept tree plus one search
     const uint32_t need = cnt + cfg.n_sims + 2 * cfg.batch_size + 64;
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     for (uint32_t base = first; base < hi; base += 64) {
         const uint32_t i = base + lane;
         uint32_t ni = NIL;
-        if (i < hi) ni = __hip_atomic_load(&m.fwd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < hi) ni = __hip_atomic_load(&m.fwd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         NodeStats nd;
         NodeKids kd;
         if (ni != NIL) {
@@ -400,10 +405,10 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
             kd = m.kids[i];
             nd.h1.parent = i == keep_root ? NIL
                                           : __hip_atomic_load(&m.fwd[nd.h1.parent], __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT);
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int c = 0; c < 25; ++c)
                 if (kd.c[c] != NIL)
-                    kd.c[c] = __hip_atomic_load(&m.fwd[kd.c[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    kd.c[c] = __hip_atomic_load(&m.fwd[kd.c[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();  // every lane has read its node before any lane overwrites a source
         if (ni != NIL) {

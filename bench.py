@@ -31,6 +31,12 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes of the tree kernels
 B_NODE_VISIT, B_NEW_NODE, B_NN_LEAF = 300, 304, 1444
+# HBM traffic of one k_gather launch at the default workload, from the PMC passes committed in
+# profiles/r01_v6_pmc_hbm_traffic_default.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs):
+# FETCH_SIZE 551 052 KB per dispatch, doubled as MI355X_MICROARCH.md prescribes for gfx950 (the factor is
+# calibrated for wide streaming reads; these are scattered 16-byte reads, so it is an upper bound),
+# WRITE_SIZE 540 052 KB per dispatch as read.
+PMC_GATHER_FETCH_KB, PMC_GATHER_WRITE_KB = 551052.0, 540052.0
 B_SELECT_VISIT = 204  # the select half of SURVEY 8d's 300 B node-visit (192 B read + 12 B virtual-loss writes)
 B_LEAF_REQ = 40  # one evaluator request written by the gather: position + slot id
 
@@ -233,7 +239,12 @@ def main() -> int:
         "node_visits_per_sec": tot["nv"] / elapsed,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            # PMC counters cannot be read inside this process: the figure is the committed measurement of this
+            # exact workload (same games / resident / evaluator), null for any other
+            "traffic": ((2.0 * PMC_GATHER_FETCH_KB + PMC_GATHER_WRITE_KB) * 1024.0
+                        if (kernel == "k_gather" and args.games == 262144 and min(args.resident, args.games) == 65536)
+                        else None),
+            "traffic_source": "profiles/r01_v6_pmc_hbm_traffic_default.txt (bytes per k_gather launch; FETCH_SIZE x2 + WRITE_SIZE)",
             "kernel": kernel, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
             "algorithmic_bytes_per_launch": gather_bytes / launches,
             # the whole step (gather + evaluator + backup, tree reuse overlapped) for reference
