@@ -532,6 +532,114 @@ __global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n, Ba
     s.status = SLOT_ACTIVE;
 }
 
+// ------------------------------------------------------------------------------------------------
+// NN-evaluation cache (cached_backend.rs:70-130, nn_cache.rs): positions that were evaluated before
+// skip the network. The reference keeps one FIFO table per worker thread keyed by a 64-bit FNV-1a
+// hash of everything the network sees; here one device-wide open-addressing table serves all games,
+// indexed by the same kind of hash but matched on the full position, so a hit is exact. A hit returns
+// bit for bit what the network kernel would compute again (it is deterministic per leaf), so game
+// records do not depend on the cache, only the work does.
+//   k_cache_probe: every queued leaf looks itself up (<= CACHE_PROBES slots from its home slot); hits
+//     get their result at once, misses are compacted into a second queue for the network;
+//   k_cache_fill:  results of the misses go to their place in the batch and into the table (first empty
+//     slot of the probe window, else the home slot is overwritten). Writers claim a slot by CAS on its
+//     tag; readers only run in k_cache_probe, i.e. after a kernel boundary, and never see a slot mid-write.
+enum { CACHE_PROBES = 8, CACHE_EMPTY = 0, CACHE_VALID = 1, CACHE_BUSY = 2 };
+template <int NW>
+struct alignas(16) CacheEntry {
+    State<NW> st;
+    uint32_t maze_off;
+    uint32_t tag;
+    EvalOut ev;
+};
+template <int NW>
+__device__ inline uint64_t position_hash(const State<NW>& st, uint32_t maze_off) {  // FNV-1a, cached_backend.rs:135-199
+    uint64_t h = 0xcbf29ce484222325ULL;
+    auto mix = [&](uint64_t v) {
+        h ^= v;
+        h *= 0x100000001b3ULL;
+    };
+    mix(st.p1);
+    mix(st.p2);
+    mix(__float_as_uint(st.s1));
+    mix(__float_as_uint(st.s2));
+    mix(st.m1);
+    mix(st.m2);
+    mix(st.turn);
+    mix(maze_off);
+    for (int w = 0; w < NW; ++w) mix(st.cheese[w]);
+    return h;
+}
+template <int NW>
+__device__ inline bool same_position(const State<NW>& a, const State<NW>& b) {
+    bool eq = a.p1 == b.p1 && a.p2 == b.p2 && a.m1 == b.m1 && a.m2 == b.m2 && a.turn == b.turn &&
+              __float_as_uint(a.s1) == __float_as_uint(b.s1) && __float_as_uint(a.s2) == __float_as_uint(b.s2);
+    for (int w = 0; w < NW; ++w) eq = eq && a.cheese[w] == b.cheese[w];
+    return eq;
+}
+template <int NW>
+__global__ void k_cache_probe(const LeafReq<NW>* queue, const uint32_t* n_ptr, const Slot<NW>* slots,
+                              const CacheEntry<NW>* table, uint64_t mask, EvalOut* ev_out, LeafReq<NW>* miss_queue,
+                              uint32_t* miss_map, uint32_t* miss_count, unsigned long long* counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const LeafReq<NW> r = queue[i];
+    const uint32_t maze_off = slots[r.slot].board.maze_off;
+    const uint64_t h = position_hash(r.st, maze_off);
+    bool hit = false;
+    for (int p = 0; p < CACHE_PROBES && !hit; ++p) {
+        const CacheEntry<NW>& e = table[(h + (uint64_t)p) & mask];
+        if (e.tag == CACHE_EMPTY) break;
+        if (e.tag == CACHE_VALID && e.maze_off == maze_off && same_position(e.st, r.st)) {
+            ev_out[i] = e.ev;
+            hit = true;
+        }
+    }
+    if (hit) {
+        atomicAdd(&counters[0], 1ULL);
+    } else {
+        const uint32_t j = atomicAdd(miss_count, 1u);
+        miss_queue[j] = r;
+        miss_map[j] = i;
+        atomicAdd(&counters[1], 1ULL);
+    }
+}
+template <int NW>
+__global__ void k_cache_fill(const LeafReq<NW>* miss_queue, const uint32_t* miss_map, const uint32_t* miss_count,
+                             const EvalOut* ev_miss, const Slot<NW>* slots, CacheEntry<NW>* table, uint64_t mask,
+                             EvalOut* ev_out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *miss_count) return;
+    const LeafReq<NW> r = miss_queue[j];
+    const EvalOut ev = ev_miss[j];
+    ev_out[miss_map[j]] = ev;
+    const uint32_t maze_off = slots[r.slot].board.maze_off;
+    const uint64_t h = position_hash(r.st, maze_off);
+    // first empty slot of the window; a position that is already there (or being written by a twin in
+    // this batch) is left alone; a full window overwrites the home slot
+    for (int p = 0; p <= CACHE_PROBES; ++p) {
+        const bool evict = p == CACHE_PROBES;
+        CacheEntry<NW>& e = table[(h + (uint64_t)(evict ? 0 : p)) & mask];
+        const uint32_t tag = e.tag;
+        if (!evict && tag == CACHE_VALID) {
+            if (e.maze_off == maze_off && same_position(e.st, r.st)) return;
+            continue;
+        }
+        if (!evict && tag == CACHE_BUSY) continue;
+        if (atomicCAS(&e.tag, evict ? (uint32_t)CACHE_VALID : (uint32_t)CACHE_EMPTY, (uint32_t)CACHE_BUSY) !=
+            (evict ? (uint32_t)CACHE_VALID : (uint32_t)CACHE_EMPTY)) {
+            if (evict) return;
+            continue;
+        }
+        e.st = r.st;
+        e.maze_off = maze_off;
+        e.ev = ev;
+        __threadfence();
+        atomicExch(&e.tag, (uint32_t)CACHE_VALID);
+        return;
+    }
+}
+
 // host-callback evaluator support: leaves out, results in (single-slot searches)
 template <int NW>
 __global__ void k_export_leaves(const Slot<NW>* slots, uint32_t slot, Bases B, State<NW>* out, uint32_t* n_out) {
@@ -845,6 +953,13 @@ struct Engine {
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
     std::vector<void*> slot_grown;  // per slot: the arena the host allocated after a stall (nullptr = none)
+    // NN-evaluation cache (k_cache_probe / k_cache_fill); cache_entries == 0: off
+    uint64_t cache_entries = 0;
+    DevBuf<CacheEntry<NW>> cache_table;
+    DevBuf<LeafReq<NW>> miss_queue;
+    DevBuf<uint32_t> miss_map, miss_count;
+    DevBuf<EvalOut> ev_miss;
+    DevBuf<unsigned long long> cache_counters;
     ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
@@ -979,6 +1094,16 @@ struct Engine {
             HIP_TRY(ev_queue.alloc((size_t)S * cfg.batch_size));
             HIP_TRY(queue_count.alloc(64));
         }
+        if (need_queue && cache_entries) {
+            HIP_TRY(cache_table.alloc(cache_entries));
+            HIP_TRY(hipMemsetAsync(cache_table.p, 0, sizeof(CacheEntry<NW>) * cache_entries, stream));
+            HIP_TRY(miss_queue.alloc((size_t)S * cfg.batch_size));
+            HIP_TRY(miss_map.alloc((size_t)S * cfg.batch_size));
+            HIP_TRY(ev_miss.alloc((size_t)S * cfg.batch_size));
+            HIP_TRY(miss_count.alloc(64));
+            HIP_TRY(cache_counters.alloc(2));
+            HIP_TRY(hipMemsetAsync(cache_counters.p, 0, 16, stream));
+        }
         if (net != nullptr) {
             const size_t per = (size_t)net->dev.hw * 4;
             if (maze_bytes.size() % per != 0) return fail(AR_E_INVALID, "maze pool does not match the network's board size");
@@ -1076,8 +1201,21 @@ struct Engine {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
         }
-        if (int rc = net_forward_queue<NW>(net, q, qc, (uint32_t)((size_t)n * cfg.batch_size), slots.p, maze.p, ev, g.stream))
+        const uint32_t n_max = (uint32_t)((size_t)n * cfg.batch_size);
+        if (cache_entries) {
+            LeafReq<NW>* mq = miss_queue.p + (size_t)g.first * cfg.batch_size;
+            uint32_t* mm = miss_map.p + (size_t)g.first * cfg.batch_size;
+            EvalOut* em = ev_miss.p + (size_t)g.first * cfg.batch_size;
+            uint32_t* mc = miss_count.p + gi;
+            HIP_TRY(hipMemsetAsync(mc, 0, 4, g.stream));
+            hipLaunchKernelGGL(k_cache_probe<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, q, qc, slots.p,
+                               cache_table.p, cache_entries - 1, ev, mq, mm, mc, cache_counters.p);
+            if (int rc = net_forward_queue<NW>(net, mq, mc, n_max, slots.p, maze.p, em, g.stream)) return rc;
+            hipLaunchKernelGGL(k_cache_fill<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, mq, mm, mc, em, slots.p,
+                               cache_table.p, cache_entries - 1, ev);
+        } else if (int rc = net_forward_queue<NW>(net, q, qc, n_max, slots.p, maze.p, ev, g.stream)) {
             return rc;
+        }
         hipLaunchKernelGGL(k_backup<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(),
                            zig.p, ev, lanes, g.first, phase);
         if (side) {
@@ -1507,6 +1645,14 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
 
     Engine<NW> eng;
     eng.net = net;
+    if (p.cache_size && net != nullptr) {
+        // the reference sizes one table per worker thread (capacity x 1.9 slots, nn_cache.rs:49); one table
+        // serves every game here, so it gets the threads' worth, rounded up to a power of two
+        const uint64_t want = (uint64_t)((double)p.cache_size * (p.num_threads ? p.num_threads : 1) * 1.9) + 1;
+        uint64_t e = 1u << 16;
+        while (e < want && e < (1ULL << 26)) e <<= 1;
+        eng.cache_entries = e;
+    }
     if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
     if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr, pool_bytes)) return rc;
     tm[0] = since(tp);
@@ -1653,6 +1799,13 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
     st.steps = eng.steps;
     st.gather_secs = eng.gather_ms / 1000.0;
     st.gather_launches = eng.gather_launches;
+    if (eng.cache_entries) {
+        unsigned long long hm[2] = {0, 0};
+        if (hipMemcpy(hm, eng.cache_counters.p, sizeof hm, hipMemcpyDeviceToHost) == hipSuccess) {
+            st.cache_hits = hm[0];
+            st.cache_misses = hm[1];
+        }
+    }
     if (timing)
         fprintf(stderr,
                 "[ar timing] games=%u resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "
@@ -1938,7 +2091,6 @@ int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink 
     if (pos != "corners" && pos != "random") return fail(AR_E_INVALID, "unknown positions: " + pos);
     if (p->width == 0 || p->height == 0 || (int)p->width * p->height > 256)
         return fail(AR_E_INVALID, "board must have 1..256 cells");
-    if (p->cache_size != 0) return fail(AR_E_INVALID, "cache_size > 0: the device NN-eval cache is not built yet");
     int dev = 0;
     if (int rc = parse_device(p->device, p->device_index, dev)) return rc;
     ArNet* net = nullptr;

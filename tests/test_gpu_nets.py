@@ -161,3 +161,31 @@ def test_device_mlp_other_hidden_widths_match_the_oracle_net(hidden, tmp_path):
     got = Net(blob).evaluate(games)
     for k in ("logits_p1", "logits_p2", "policy_p1", "policy_p2", "value_p1", "value_p2"):
         np.testing.assert_allclose(got[k], want[k], atol=1e-5, rtol=1e-5, err_msg=f"h{hidden}:{k}")
+
+
+def test_nn_eval_cache_skips_work_but_not_results():
+    """cache_size > 0 (cached_backend.rs): repeated positions are served from the device table. A hit is
+    bit for bit what the network computes again, so the records are those of the uncached run; every
+    request is either a hit or a miss."""
+    from alpharat_amd.sampling import rust_self_play
+
+    def run(cache_size):
+        games = []
+        st = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=48, simulations=300,
+                            batch_size=16, output_dir=None, seed=9, concurrent_games=32, cache_size=cache_size,
+                            weights_path=str(GOLD / "nets" / "mlp_7x7_h256.arnet"), c_puct=0.512, fpu_reduction=0.459,
+                            force_k=0.103, noise_epsilon=0.25, on_game=games.append)
+        return st, {g["game_index"]: g for g in games}
+
+    st0, base = run(0)
+    st1, cached = run(4096)
+    assert st0.cache_hits == 0 and st0.cache_misses == 0
+    assert st1.cache_hits > 0
+    assert st1.cache_hits + st1.cache_misses == st1.total_nn_evals == st0.total_nn_evals
+    assert sorted(base) == sorted(cached)
+    for i, g in base.items():
+        for key, val in g.items():
+            if isinstance(val, np.ndarray):
+                np.testing.assert_array_equal(val, cached[i][key], err_msg=f"game {i} {key}")
+            else:
+                assert val == cached[i][key], (i, key)

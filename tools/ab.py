@@ -29,10 +29,11 @@ for rep in range(repeat):
             for kv in cfg.split(","):
                 k, _, v = kv.partition("=")
                 os.environ[k] = v
+        cache = int(os.environ.pop("CACHE", "0"))  # pseudo-knob: CACHE=n passes cache_size=n
         t0 = time.perf_counter()
-        st = rust_self_play(**bench.GAME, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
+        st = rust_self_play(**bench.GAME, cache_size=cache, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
                             weights_path=str(blob), seed=0, first_game_index=0, concurrent_games=conc, **bench.SEARCH)
         dt = time.perf_counter() - t0
         print(f"[{rep}] {cfg:<44} wall={dt:7.2f}s device={st.device_secs:7.2f}s steps={st.steps} "
-              f"sims/s={st.total_simulations / dt / 1e6:7.1f}M avg_step_ms={st.device_secs / max(st.steps, 1) * 1e3:.3f}",
+              f"hits={st.cache_hit_rate:5.3f} sims/s={st.total_simulations / dt / 1e6:7.1f}M avg_step_ms={st.device_secs / max(st.steps, 1) * 1e3:.3f}",
               flush=True)
