@@ -582,26 +582,37 @@ __global__ void k_cache_probe(const LeafReq<NW>* queue, const uint32_t* n_ptr, c
                               const CacheEntry<NW>* table, uint64_t mask, EvalOut* ev_out, LeafReq<NW>* miss_queue,
                               uint32_t* miss_map, uint32_t* miss_count, unsigned long long* counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *n_ptr) return;
-    const LeafReq<NW> r = queue[i];
-    const uint32_t maze_off = slots[r.slot].board.maze_off;
-    const uint64_t h = position_hash(r.st, maze_off);
+    const bool in = i < *n_ptr;
+    LeafReq<NW> r = queue[in ? i : 0];
     bool hit = false;
-    for (int p = 0; p < CACHE_PROBES && !hit; ++p) {
-        const CacheEntry<NW>& e = table[(h + (uint64_t)p) & mask];
-        if (e.tag == CACHE_EMPTY) break;
-        if (e.tag == CACHE_VALID && e.maze_off == maze_off && same_position(e.st, r.st)) {
-            ev_out[i] = e.ev;
-            hit = true;
+    if (in) {
+        const uint32_t maze_off = slots[r.slot].board.maze_off;
+        const uint64_t h = position_hash(r.st, maze_off);
+        for (int p = 0; p < CACHE_PROBES && !hit; ++p) {
+            const CacheEntry<NW>& e = table[(h + (uint64_t)p) & mask];
+            if (e.tag == CACHE_EMPTY) break;
+            if (e.tag == CACHE_VALID && e.maze_off == maze_off && same_position(e.st, r.st)) {
+                ev_out[i] = e.ev;
+                hit = true;
+            }
         }
     }
-    if (hit) {
-        atomicAdd(&counters[0], 1ULL);
-    } else {
-        const uint32_t j = atomicAdd(miss_count, 1u);
+    // one atomic per wavefront for the counters and for the misses' places in the second queue
+    const unsigned long long hits = __ballot(in && hit), misses = __ballot(in && !hit);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (hits) atomicAdd(&counters[0], (unsigned long long)__popcll(hits));
+        if (misses) {
+            atomicAdd(&counters[1], (unsigned long long)__popcll(misses));
+            base = atomicAdd(miss_count, (uint32_t)__popcll(misses));
+        }
+    }
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (in && !hit) {
+        const uint32_t j = base + (uint32_t)__popcll(misses & ((1ULL << lane) - 1ULL));
         miss_queue[j] = r;
         miss_map[j] = i;
-        atomicAdd(&counters[1], 1ULL);
     }
 }
 template <int NW>
