@@ -174,6 +174,17 @@ __device__ inline uint32_t tag_status(uint32_t st, uint32_t phase) {
     return st == SLOT_STALL ? (uint32_t)SLOT_STALL_B : st == SLOT_ADVANCE ? (uint32_t)SLOT_ADVANCE_B : st;
 }
 
+// per-game mazes (generated mazes): maze i of the upload goes to the pool entry of the slot game i starts in
+template <int NW>
+__global__ void k_place_mazes(const GameInit<NW>* init, uint32_t n, const uint8_t* stage, uint32_t stride, uint8_t* pool,
+                              uint32_t* ids_out) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = init[i].slot;
+    for (uint32_t b = threadIdx.x; b < stride; b += blockDim.x) pool[(size_t)slot * stride + b] = stage[(size_t)i * stride + b];
+    if (threadIdx.x == 0) ids_out[i] = slot;
+}
+
 template <int NW>
 __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t n, Bases B, SearchCfg cfg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,6 +694,7 @@ struct HostGame {
     float s1, s2;
     std::vector<uint8_t> cheese;  // [hw]
     uint16_t total_cheese;
+    std::vector<uint8_t> cost;    // [hw * 4] this game's generated maze; empty = the run's shared maze
 };
 
 // 180-degree-symmetric cheese: shuffle the pair representatives (i < N-1-i, start cells excluded)
@@ -742,6 +754,79 @@ std::vector<uint8_t> open_maze_cost(int w, int h) {
             p[DIR_DOWN] = y > 0;
             p[DIR_LEFT] = x > 0;
         }
+    return c;
+}
+
+// Random walls + mud: the reference delegates to the pyrat-rust engine (absent, own RNG), so this is our
+// own generator -- specification in DESIGN.md "game generation", second implementation in
+// oracle/pyrat_engine.hpp::make_maze (the two are compared game by game in the parity tests).
+std::vector<uint8_t> generate_maze(int w, int h, float wall_density, float mud_density, bool symmetric, uint64_t seed) {
+    HostRng rng(seed ^ 0x6D617A65ULL);
+    const int n = w * h;
+    std::vector<std::pair<int, int>> ed;  // (a, b), a < b; per cell: RIGHT then UP
+    std::vector<int> right_of(n, -1), up_of(n, -1);
+    for (int i = 0; i < n; ++i) {
+        if (i % w + 1 < w) {
+            right_of[i] = (int)ed.size();
+            ed.emplace_back(i, i + 1);
+        }
+        if (i / w + 1 < h) {
+            up_of[i] = (int)ed.size();
+            ed.emplace_back(i, i + w);
+        }
+    }
+    const int ne = (int)ed.size();
+    std::vector<int> image(ne);
+    for (int k = 0; k < ne; ++k) {
+        if (!symmetric) {
+            image[k] = k;
+            continue;
+        }
+        const int a = n - 1 - ed[k].second, b = n - 1 - ed[k].first;  // a < b again
+        image[k] = b == a + 1 ? right_of[a] : up_of[a];
+    }
+    std::vector<uint8_t> val(ne, 1);
+    const uint32_t wall_thr = (uint32_t)(wall_density * 16777216.0f), mud_thr = (uint32_t)(mud_density * 16777216.0f);
+    for (int k = 0; k < ne; ++k)
+        if (k <= image[k] && rng.below(1u << 24) < wall_thr) val[k] = val[image[k]] = 0;
+    std::vector<int> up(n);
+    for (int i = 0; i < n; ++i) up[i] = i;
+    int comps = n;
+    auto root = [&](int v) {
+        while (up[v] != v) v = up[v] = up[up[v]];
+        return v;
+    };
+    auto join = [&](int a, int b) {
+        a = root(a);
+        b = root(b);
+        if (a == b) return;
+        if (a < b) up[b] = a;
+        else up[a] = b;
+        --comps;
+    };
+    for (int k = 0; k < ne; ++k)
+        if (val[k]) join(ed[k].first, ed[k].second);
+    std::vector<int> closed;
+    for (int k = 0; k < ne; ++k)
+        if (k <= image[k] && !val[k]) closed.push_back(k);
+    for (int i = (int)closed.size() - 1; i >= 1; --i) std::swap(closed[i], closed[rng.below((uint32_t)i + 1)]);
+    for (int k : closed) {
+        if (comps == 1) break;
+        const int m = image[k];
+        if (root(ed[k].first) == root(ed[k].second) && root(ed[m].first) == root(ed[m].second)) continue;
+        val[k] = val[m] = 1;
+        join(ed[k].first, ed[k].second);
+        join(ed[m].first, ed[m].second);
+    }
+    for (int k = 0; k < ne; ++k)
+        if (k <= image[k] && val[k] && rng.below(1u << 24) < mud_thr) val[k] = val[image[k]] = (uint8_t)(2 + rng.below(2));
+    std::vector<uint8_t> c((size_t)n * 4, 0);
+    for (int k = 0; k < ne; ++k) {
+        const int a = ed[k].first, b = ed[k].second;
+        const int d = b == a + 1 ? DIR_RIGHT : DIR_UP;
+        c[(size_t)a * 4 + d] = val[k];
+        c[(size_t)b * 4 + ((d + 2) & 3)] = val[k];
+    }
     return c;
 }
 
@@ -964,6 +1049,11 @@ struct Engine {
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
     std::vector<void*> slot_grown;  // per slot: the arena the host allocated after a stall (nullptr = none)
+    // generated mazes: one pool entry per slot, rewritten when a new game starts there (open mazes: one shared entry)
+    bool per_slot_maze = false;
+    uint32_t maze_stride = 0;
+    DevBuf<uint8_t> maze_stage;
+    DevBuf<uint32_t> maze_ids;
     // NN-evaluation cache (k_cache_probe / k_cache_fill); cache_entries == 0: off
     uint64_t cache_entries = 0;
     DevBuf<CacheEntry<NW>> cache_table;
@@ -1126,7 +1216,8 @@ struct Engine {
 
     uint32_t grid(uint32_t n) const { return (n + 63) / 64; }
 
-    int start_games(std::vector<GameInit<NW>>& games) {
+    // `mazes`: games.size() x maze_stride bytes when per_slot_maze
+    int start_games(std::vector<GameInit<NW>>& games, const std::vector<uint8_t>* mazes = nullptr) {
         if (games.empty()) return AR_OK;
         for (GameInit<NW>& g : games) {  // a new game starts in the slot's first arena again
             g.reset_arena = 0;
@@ -1137,6 +1228,18 @@ struct Engine {
             }
         }
         HIP_TRY(hipMemcpyAsync(init.p, games.data(), sizeof(GameInit<NW>) * games.size(), hipMemcpyHostToDevice, stream));
+        if (per_slot_maze) {
+            if (!mazes || mazes->size() != games.size() * (size_t)maze_stride) return fail(AR_E_INVALID, "internal: mazes missing");
+            if (!maze_stage.p) {
+                HIP_TRY(maze_stage.alloc((size_t)S * maze_stride));
+                HIP_TRY(maze_ids.alloc(S));
+            }
+            HIP_TRY(hipMemcpyAsync(maze_stage.p, mazes->data(), mazes->size(), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_place_mazes<NW>, dim3((uint32_t)games.size()), dim3(64), 0, stream, init.p,
+                               (uint32_t)games.size(), maze_stage.p, maze_stride, maze.p, maze_ids.p);
+            if (net != nullptr)
+                if (int rc = net_rebind_mazes(net, maze_ids.p, (int)games.size(), stream)) return rc;
+        }
         hipLaunchKernelGGL(k_init_games<NW>, dim3(grid((uint32_t)games.size())), dim3(64), 0, stream, slots.p, init.p,
                            (uint32_t)games.size(), bases(), cfg);
         HIP_TRY(hipGetLastError());
@@ -1602,8 +1705,15 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
         rseed = ((uint64_t)rd() << 32) | rd();
     }
     const bool random_pos = p.positions && std::string(p.positions) == "random";
+    // "classic" = the engine's default walls and mud (bindings.rs:507 with_classic_maze; taken here as density
+    // 0.7 / 0.1, symmetric -- the defaults of the binding's own signature), "random" = the caller's parameters
+    const std::string maze_type = p.maze_type ? p.maze_type : "open";
+    const bool gen_maze = maze_type != "open";
+    const float wall_d = maze_type == "classic" ? 0.7f : p.wall_density, mud_d = maze_type == "classic" ? 0.1f : p.mud_density;
+    const bool maze_sym = maze_type == "classic" ? true : p.maze_symmetric != 0;
 
     auto make_game = [&](uint32_t index, HostGame& g, std::string& err) -> bool {
+        if (gen_maze) g.cost = generate_maze(p.width, p.height, wall_d, mud_d, maze_sym, gseed + index);
         g.width = p.width;
         g.height = p.height;
         g.max_turns = p.max_turns;
@@ -1665,7 +1775,13 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
         eng.cache_entries = e;
     }
     if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
-    if (int rc = eng.setup(device, S, cfg, p.max_turns, cost, arena_nodes, net != nullptr, pool_bytes)) return rc;
+    eng.per_slot_maze = gen_maze;
+    eng.maze_stride = (uint32_t)hw * 4u;
+    {
+        // generated mazes: one pool entry per slot (filled when a game starts there); open: the one shared maze
+        const std::vector<uint8_t> pool_init = gen_maze ? std::vector<uint8_t>((size_t)S * hw * 4, (uint8_t)0) : cost;
+        if (int rc = eng.setup(device, S, cfg, p.max_turns, pool_init, arena_nodes, net != nullptr, pool_bytes)) return rc;
+    }
     tm[0] = since(tp);
     // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
     eng.gather_rounds = default_gather_rounds(cfg);
@@ -1699,6 +1815,7 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
 
     auto refill = [&](const std::vector<uint32_t>& free_slots) -> int {
         std::vector<GameInit<NW>> inits;
+        std::vector<uint8_t> mazes;
         for (uint32_t sl : free_slots) {
             if (next_game >= p.num_games) break;
             const uint32_t index = p.first_game_index + next_game;
@@ -1706,7 +1823,8 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
             if (!make_game(index, g, err)) return fail(AR_E_INVALID, err);
             GameInit<NW> gi;
             memset(&gi, 0, sizeof gi);
-            fill_state<NW>(g, gi.board, gi.st, 0);
+            fill_state<NW>(g, gi.board, gi.st, gen_maze ? sl * eng.maze_stride : 0u);
+            if (gen_maze) mazes.insert(mazes.end(), g.cost.begin(), g.cost.end());
             gi.rng_seed = rseed + index;
             gi.game_index = index;
             gi.slot = sl;
@@ -1715,7 +1833,7 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
             slot_game[sl] = std::move(g);
             ++next_game;
         }
-        return eng.start_games(inits);
+        return eng.start_games(inits, gen_maze ? &mazes : nullptr);
     };
 
     {
@@ -1758,7 +1876,8 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
             for (uint32_t d = 0; d < n_done; ++d) {
                 const DoneInfo<NW>& di = eng.h_info.p[d];
                 auto rec = std::make_shared<GameRecordHost>();
-                record_from_device<NW>(di, eng.h_staging.p + (size_t)d * p.max_turns, slot_game[di.slot], cost, *rec);
+                const HostGame& hg = slot_game[di.slot];
+                record_from_device<NW>(di, eng.h_staging.p + (size_t)d * p.max_turns, hg, hg.cost.empty() ? cost : hg.cost, *rec);
                 // SelfPlayStats::add_game (selfplay.rs:190-210)
                 st.total_games += 1;
                 st.total_positions += rec->n;
@@ -2094,9 +2213,7 @@ int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink 
     if (!p || !out) return fail(AR_E_INVALID, "null argument");
     const std::string mt = p->maze_type ? p->maze_type : "open";
     if (mt != "open") {
-        if (mt == "classic" || mt == "random")
-            return fail(AR_E_INVALID, "maze_type '" + mt + "' is not generated on the device yet (open mazes only)");
-        return fail(AR_E_INVALID, "unknown maze_type: " + mt);
+        if (mt != "classic" && mt != "random") return fail(AR_E_INVALID, "unknown maze_type: " + mt);
     }
     const std::string pos = p->positions ? p->positions : "corners";
     if (pos != "corners" && pos != "random") return fail(AR_E_INVALID, "unknown positions: " + pos);

@@ -321,10 +321,11 @@ __device__ inline void softmax5(const float* l, float* p) {
 __device__ inline float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // per-maze first-layer constant: cmaze[m][n] = b1[n] + sum_{i < hw*4} maze_val(i) * w1t[i][n]
+// `ids` (optional): the mazes to (re)compute, one block each; without it block m computes maze m
 __global__ void k_maze_const(const float* w1t, const float* b1, int H, int hw, const uint8_t* maze_pool, int n_mazes,
-                             float* cmaze) {
-    const int m = blockIdx.x;
-    if (m >= n_mazes) return;
+                             float* cmaze, const uint32_t* ids = nullptr) {
+    if ((int)blockIdx.x >= n_mazes) return;
+    const int m = ids ? (int)ids[blockIdx.x] : (int)blockIdx.x;
     const uint8_t* cost = maze_pool + (size_t)m * hw * 4;
     for (int n = threadIdx.x; n < H; n += blockDim.x) {
         float acc = b1[n];
@@ -980,6 +981,15 @@ static int net_bind_mazes(ArNet* net, const uint8_t* d_maze_pool, int n_mazes, h
     net->dev.n_mazes = n_mazes;
     net->bound_pool = d_maze_pool;
     net->bound_mazes = n_mazes;
+    return AR_OK;
+}
+
+// mazes `d_ids[0..n)` of the bound pool changed (a slot got a new game): refresh their first-layer constants
+static int net_rebind_mazes(ArNet* net, const uint32_t* d_ids, int n, hipStream_t stream) {
+    if (n <= 0 || net->dev.arch == arnet::ARCH_CNN || !net->cmaze) return AR_OK;
+    hipLaunchKernelGGL(arnet::k_maze_const, dim3(n), dim3(256), 0, stream, net->dev.w1t, net->dev.b1, net->dev.H,
+                       net->dev.hw, net->bound_pool, n, net->cmaze, d_ids);
+    if (hipGetLastError() != hipSuccess) return nets_fail(AR_E_DEVICE, "k_maze_const launch failed");
     return AR_OK;
 }
 

@@ -127,7 +127,7 @@ typedef struct ArSelfPlayParams {
     uint16_t cheese_count, max_turns;
     uint32_t num_games;
     int cheese_symmetric;       /* default 1 */
-    const char* maze_type;      /* "open" (classic / random: AR_E_INVALID until the generator lands) */
+    const char* maze_type;      /* "open" | "classic" | "random" (generated mazes: our own seeded generator) */
     const char* positions;      /* "corners" | "random" */
     float wall_density, mud_density;
     int maze_symmetric;

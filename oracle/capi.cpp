@@ -72,6 +72,13 @@ void or_game_add_cheese(void* g, int x, int y) { ((GameState*)g)->add_cheese(x, 
 int or_game_random_cheese(void* g, uint16_t count, int symmetric, uint64_t seed) {
     return make_cheese(*(GameState*)g, count, symmetric != 0, seed);
 }
+void or_game_random_maze(void* g, float wall_density, float mud_density, int symmetric, uint64_t seed) {
+    make_maze(*(GameState*)g, wall_density, mud_density, symmetric != 0, seed);
+}
+void or_game_cost(const void* gp, uint8_t* out) {  // [cells * 4]: 0 wall / edge, 1 open, >= 2 mud
+    const GameState* g = (const GameState*)gp;
+    std::memcpy(out, g->cost, (size_t)g->cells() * 4);
+}
 void or_game_make_move(void* g, uint8_t d1, uint8_t d2) { ((GameState*)g)->make_move(d1, d2); }
 int or_game_over(const void* g) { return ((const GameState*)g)->check_game_over(); }
 // state: [p1x,p1y,p2x,p2y,p1mud,p2mud,turn,remaining] + scores

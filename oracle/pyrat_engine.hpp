@@ -253,4 +253,85 @@ inline bool make_cheese(GameState& g, uint16_t count, bool symmetric, uint64_t s
     return true;
 }
 
+
+// Random walls + mud. The reference delegates this to the pyrat-rust engine (GameBuilder::with_random_maze /
+// with_classic_maze, bindings.rs:505-517), whose generator and RNG (rand 0.10) are not in the container:
+// PARITY UNPINNED. This is our own generator, specified in DESIGN.md "game generation" and implemented
+// twice (here and in alpharat_hip.hip::generate_maze):
+//   edges in the order (cell 0..n-1: RIGHT edge, then UP edge); with symmetry an edge and its 180-degree
+//   image (cells i -> n-1-i) are decided together, the one with the smaller index deciding;
+//   1. every deciding edge becomes a wall when below(2^24) < (u32)(wall_density * 2^24);
+//   2. the walled deciding edges are shuffled (Fisher-Yates, gen_range) and opened again, in that order,
+//      whenever they (or their image) join two components, until the maze is connected;
+//   3. every open deciding edge gets mud when below(2^24) < (u32)(mud_density * 2^24), cost 2 + below(2).
+// Stream: SmallRng::seed_from_u64(seed ^ 0x6D617A65).
+inline void make_maze(GameState& g, float wall_density, float mud_density, bool symmetric, uint64_t seed) {
+    SmallRng rng = SmallRng::seed_from_u64(seed ^ 0x6D617A65ULL);
+    const int w = g.width, h = g.height, n = w * h;
+    struct E {
+        int a, b;
+    };
+    std::vector<E> edges;
+    for (int i = 0; i < n; ++i) {
+        const int x = i % w, y = i / w;
+        if (x + 1 < w) edges.push_back({i, i + 1});
+        if (y + 1 < h) edges.push_back({i, i + w});
+    }
+    auto find_edge = [&](int a, int b) {
+        for (size_t k = 0; k < edges.size(); ++k)
+            if (edges[k].a == a && edges[k].b == b) return (int)k;
+        return -1;
+    };
+    std::vector<int> image(edges.size());
+    for (size_t k = 0; k < edges.size(); ++k) image[k] = symmetric ? find_edge(n - 1 - edges[k].b, n - 1 - edges[k].a) : (int)k;
+    std::vector<uint8_t> value(edges.size(), 1);  // 0 wall, 1 open, >= 2 mud
+    std::vector<int> deciding;
+    for (size_t k = 0; k < edges.size(); ++k)
+        if ((int)k <= image[k]) deciding.push_back((int)k);
+    const uint32_t wall_thr = (uint32_t)(wall_density * 16777216.0f), mud_thr = (uint32_t)(mud_density * 16777216.0f);
+    for (int k : deciding)
+        if (rng.gen_range_u32(1u << 24) < wall_thr) value[k] = value[image[k]] = 0;
+    std::vector<int> parent(n);
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto root = [&](int v) {
+        while (parent[v] != v) v = parent[v] = parent[parent[v]];
+        return v;
+    };
+    int comps = n;
+    auto join = [&](int a, int b) {
+        a = root(a);
+        b = root(b);
+        if (a == b) return false;
+        parent[a < b ? b : a] = a < b ? a : b;
+        comps -= 1;
+        return true;
+    };
+    for (size_t k = 0; k < edges.size(); ++k)
+        if (value[k]) join(edges[k].a, edges[k].b);
+    std::vector<int> walled;
+    for (int k : deciding)
+        if (!value[k]) walled.push_back(k);
+    for (int i = (int)walled.size() - 1; i >= 1; --i) {
+        const int j = (int)rng.gen_range_u32((uint32_t)i + 1);
+        const int t = walled[i];
+        walled[i] = walled[j];
+        walled[j] = t;
+    }
+    for (int k : walled) {
+        if (comps == 1) break;
+        const int m = image[k];
+        const bool split = root(edges[k].a) != root(edges[k].b) || root(edges[m].a) != root(edges[m].b);
+        if (!split) continue;
+        value[k] = value[m] = 1;
+        join(edges[k].a, edges[k].b);
+        join(edges[m].a, edges[m].b);
+    }
+    for (int k : deciding)
+        if (value[k] && rng.gen_range_u32(1u << 24) < mud_thr) value[k] = value[image[k]] = (uint8_t)(2 + rng.gen_range_u32(2));
+    for (size_t k = 0; k < edges.size(); ++k) {
+        const int a = edges[k].a, b = edges[k].b;
+        g.set_edge(a % w, a / w, b % w, b / w, value[k]);
+    }
+}
+
 }  // namespace oracle

@@ -92,6 +92,8 @@ def lib() -> C.CDLL:
         "or_game_add_mud": (i32, [vp, i32, i32, i32, i32, i32]),
         "or_game_add_cheese": (None, [vp, i32, i32]),
         "or_game_random_cheese": (i32, [vp, u16, i32, u64]),
+        "or_game_random_maze": (None, [vp, C.c_float, C.c_float, i32, u64]),
+        "or_game_cost": (None, [vp, vp]),
         "or_game_make_move": (None, [vp, u8, u8]),
         "or_game_over": (i32, [vp]),
         "or_game_state": (None, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
@@ -172,6 +174,16 @@ class Game:
     def random_cheese(self, count, symmetric=True, seed=0):
         assert lib().or_game_random_cheese(self.g, count, int(symmetric), seed)
         return self
+
+    def random_maze(self, wall_density=0.7, mud_density=0.1, symmetric=True, seed=0):
+        """Own generator (the engine's is absent): oracle/pyrat_engine.hpp make_maze. Call before random_cheese."""
+        lib().or_game_random_maze(self.g, wall_density, mud_density, int(symmetric), seed)
+        return self
+
+    def cost(self) -> np.ndarray:
+        out = np.zeros((self.h, self.w, 4), np.uint8)
+        lib().or_game_cost(self.g, _ptr(out))
+        return out
 
     def make_move(self, d1, d2):
         lib().or_game_make_move(self.g, d1, d2)

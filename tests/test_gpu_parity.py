@@ -1,5 +1,7 @@
 """-m gpu: the HIP path, called through the C-ABI, against the CPU oracle on the same seeded inputs.
 Bar: bit-exact (visit counts, policies, values, selected actions, whole-game records)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -254,3 +256,58 @@ def test_arena_block_is_reused_and_released_between_calls():
             np.testing.assert_array_equal(a[i]["policy_p1"], other[i]["policy_p1"])
             np.testing.assert_array_equal(a[i]["visit_counts_p2"], other[i]["visit_counts_p2"])
             np.testing.assert_array_equal(a[i]["value_p1"], other[i]["value_p1"])
+
+
+@pytest.mark.parametrize("maze_type,w,h,cheese,turns,extra", [
+    ("classic", 5, 5, 5, 30, dict()),                                           # configs/game/5x5_classic.yaml
+    ("random", 7, 7, 10, 50, dict(wall_density=0.5, mud_density=0.3, maze_symmetric=False)),
+    ("random", 11, 9, 12, 60, dict(wall_density=0.8, mud_density=0.2, maze_symmetric=True)),  # > 64 cells
+])
+def test_selfplay_generated_mazes_bit_exact(maze_type, w, h, cheese, turns, extra):
+    """Walls and mud from the seeded generator (own: the engine's is absent, DESIGN.md 'game generation'),
+    one maze per game living in the slot's pool entry: mazes and whole records equal the oracle's, which
+    generates them with its own implementation of the same specification."""
+    from alpharat_amd.sampling import rust_self_play
+
+    games = []
+    n_games = 20
+    stats = rust_self_play(width=w, height=h, cheese_count=cheese, max_turns=turns, num_games=n_games, simulations=150,
+                           batch_size=8, output_dir=None, seed=0, concurrent_games=8, maze_type=maze_type,
+                           on_game=games.append, **extra)
+    assert stats.total_games == n_games
+    wd, md, sym = ((0.7, 0.1, True) if maze_type == "classic"
+                   else (extra["wall_density"], extra["mud_density"], extra["maze_symmetric"]))
+    cfg = O.make_config()
+    seen_wall = seen_mud = False
+    for g in games:
+        i = g["game_index"]
+        og = O.Game(w, h, turns).random_maze(wd, md, sym, i).random_cheese(cheese, True, i)
+        _check_game(g, O.play_game(og, cfg, 150, 8, 0xA1FA0000 + i))
+        interior = g["maze"][:-1, :-1, :2]  # UP / RIGHT of cells that have those neighbours
+        seen_wall |= bool((interior == -1).any())
+        seen_mud |= bool((g["maze"] >= 2).any())
+    assert seen_wall and seen_mud
+
+
+def test_selfplay_generated_mazes_with_network_uses_each_games_maze():
+    """With a network the first-layer maze constants are refreshed for every slot that gets a new game:
+    the root prior recorded at move 0 equals the network's policy for that game's own maze."""
+    from alpharat_amd.game import PyRat
+    from alpharat_amd.nets import Net
+    from alpharat_amd.sampling import rust_self_play
+
+    blob = Path(__file__).parent / "golden" / "nets" / "mlp_7x7_h256.arnet"
+    games = []
+    rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=24, simulations=64, batch_size=8,
+                   output_dir=None, seed=4, concurrent_games=6, maze_type="random", wall_density=0.6, mud_density=0.2,
+                   weights_path=str(blob), on_game=games.append)
+    net = Net(blob)
+    for g in games:
+        cost = np.where(g["maze"] < 0, 0, g["maze"]).astype(np.uint8)
+        start = PyRat(7, 7, cost, g["initial_cheese"].astype(np.uint8), tuple(g["p1_pos"][0]), tuple(g["p2_pos"][0]), 50)
+        out = net.evaluate([start])
+        # prior_p* are in action space with blocked moves folded onto STAY (expand_prior): compare the mass
+        # of the moves that are open for both
+        np.testing.assert_allclose(g["prior_p1"][0].sum(), 1.0, atol=1e-5)
+        open1 = [d for d in range(4) if cost[g["p1_pos"][0][1], g["p1_pos"][0][0], d] > 0]
+        np.testing.assert_allclose(g["prior_p1"][0][open1], out["policy_p1"][0][open1], atol=2e-6)
