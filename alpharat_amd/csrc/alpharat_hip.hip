@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <deque>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <random>
 #include <string>
@@ -1049,6 +1050,14 @@ struct Engine {
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
     std::vector<void*> slot_grown;  // per slot: the arena the host allocated after a stall (nullptr = none)
+    // host-allocated arenas are recycled by size instead of going back to the driver (hipMalloc + hipFree of
+    // a few MB cost ~0.3 ms together, thousands of times per run when the overflow pool runs dry)
+    std::vector<uint32_t> slot_grown_cap;
+    std::multimap<uint32_t, void*> spare_arenas;  // cap -> block
+    void retire_arena(uint32_t slot) {
+        if (slot_grown[slot]) spare_arenas.emplace(slot_grown_cap[slot], slot_grown[slot]);
+        slot_grown[slot] = nullptr;
+    }
     // generated mazes: one pool entry per slot, rewritten when a new game starts there (open mazes: one shared entry)
     bool per_slot_maze = false;
     uint32_t maze_stride = 0;
@@ -1093,6 +1102,7 @@ struct Engine {
         }
         for (void* p : slot_grown)
             if (p) hipFree(p);
+        for (auto& kv : spare_arenas) hipFree(kv.second);
         for (hipEvent_t e : gather_ev) hipEventDestroy(e);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
@@ -1132,6 +1142,7 @@ struct Engine {
         L = make_layout<NW>(cfg, max_turns);
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
+        slot_grown_cap.assign(S, 0u);
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
@@ -1222,8 +1233,7 @@ struct Engine {
         for (GameInit<NW>& g : games) {  // a new game starts in the slot's first arena again
             g.reset_arena = 0;
             if (slot_grown[g.slot]) {
-                hipFree(slot_grown[g.slot]);  // the slot was drained: no kernel touches that arena any more
-                slot_grown[g.slot] = nullptr;
+                retire_arena(g.slot);  // the slot was drained: no kernel touches that arena any more
                 g.reset_arena = 1;
             }
         }
@@ -1415,11 +1425,7 @@ struct Engine {
             HIP_TRY(hipMemcpyAsync(h_release.p, release_list.p, 4 * n_rel, hipMemcpyDeviceToHost, stream));
             hipLaunchKernelGGL(k_clear_release<NW>, dim3(grid(n_rel)), dim3(64), 0, stream, slots.p, release_list.p, n_rel);
             HIP_TRY(hipStreamSynchronize(stream));
-            for (uint32_t i = 0; i < n_rel; ++i) {
-                void*& p = slot_grown[h_release.p[i]];
-                if (p) hipFree(p);
-                p = nullptr;
-            }
+            for (uint32_t i = 0; i < n_rel; ++i) retire_arena(h_release.p[i]);
         }
         if (timed) {
             float ms = 0.0f;
@@ -1451,17 +1457,22 @@ struct Engine {
         HIP_TRY(hipMemcpyAsync(h_stall.p, stall_info.p, sizeof(StallInfo) * n_stall, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         std::vector<GrowReq> reqs(n_stall);
-        std::vector<void*> old_arenas;
+        std::vector<std::pair<uint32_t, void*>> old_arenas;
         for (uint32_t i = 0; i < n_stall; ++i) {
             const StallInfo& si = h_stall.p[i];
             uint32_t ncap = si.cap * 2;
             while (ncap < si.need) ncap *= 2;
             unsigned char* na = nullptr;
+            const auto spare = spare_arenas.find(ncap);
+            if (spare != spare_arenas.end()) {
+                na = (unsigned char*)spare->second;
+                spare_arenas.erase(spare);
+            }
             // keep a reserve: the runtime allocates kernel scratch and queues from the same memory
             size_t free_b = 0, total_b = 0;
-            const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
-                              free_b > arena_bytes(ncap) + ((size_t)3 << 30);
-            if (!room || hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess) {
+            const bool room = na != nullptr || (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                                                free_b > arena_bytes(ncap) + ((size_t)3 << 30));
+            if (!room || (na == nullptr && hipMalloc((void**)&na, arena_bytes(ncap) + 256) != hipSuccess)) {
                 (void)hipGetLastError();
                 if (may_wait) {
                     n_stall = i;  // the rest waits for blocks to come back
@@ -1471,8 +1482,9 @@ struct Engine {
                 return fail(AR_E_NOMEM, "out of device memory while growing a tree arena to " + std::to_string(ncap) +
                                             " nodes");
             }
-            if (slot_grown[si.slot]) old_arenas.push_back(slot_grown[si.slot]);
+            if (slot_grown[si.slot]) old_arenas.emplace_back(slot_grown_cap[si.slot], slot_grown[si.slot]);
             slot_grown[si.slot] = na;
+            slot_grown_cap[si.slot] = ncap;
             GrowReq r;
             r.slot = si.slot;
             r.cap = ncap;
@@ -1490,7 +1502,7 @@ struct Engine {
         hipLaunchKernelGGL(k_apply_grow<NW>, dim3(grid(n_stall)), dim3(64), 0, stream, slots.p, grow.p, n_stall, bases());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
-        for (void* p : old_arenas) hipFree(p);
+        for (auto& kv : old_arenas) spare_arenas.emplace(kv.first, kv.second);  // the copies are done (sync above)
         grows += n_stall;
         return AR_OK;
     }

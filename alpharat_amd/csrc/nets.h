@@ -999,7 +999,8 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     using namespace arnet;
     if (n_max == 0) return AR_OK;
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
-    const int tile = mlp_mfma ? 32 * MLP_MFMA_MT : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
+    static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
+    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_CNN) {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_cnn<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1008,12 +1009,16 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
         hipLaunchKernelGGL(k_cnn<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max, boards,
                            board_stride, net->bound_pool, out, logits);
     } else if (mlp_mfma) {
-        const size_t smem = (size_t)32 * MLP_MFMA_MT * (net->dev.H + 4) * 4;
-        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_mlp_mfma<NW, MLP_MFMA_MT>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        const size_t smem = (size_t)32 * mlp_mt * (net->dev.H + 4) * 4;
+        const void* fn = mlp_mt == 1 ? (const void*)k_mlp_mfma<NW, 1> : (const void*)k_mlp_mfma<NW, 2>;
+        if (smem > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
-        hipLaunchKernelGGL((k_mlp_mfma<NW, MLP_MFMA_MT>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount,
-                           n_max, boards, board_stride, out, logits);
+        if (mlp_mt == 1)
+            hipLaunchKernelGGL((k_mlp_mfma<NW, 1>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max,
+                               boards, board_stride, out, logits);
+        else
+            hipLaunchKernelGGL((k_mlp_mfma<NW, 2>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max,
+                               boards, board_stride, out, logits);
     } else if (net->dev.arch == ARCH_MLP) {
         if (net->smem > 48 * 1024 &&
             hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) !=

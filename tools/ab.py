@@ -20,7 +20,7 @@ conc = int(conc or games)
 repeat = int(sys.argv[2])
 configs = sys.argv[3:]
 blob = bench.make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet")
-knobs = ("AR_GATHER_ROUNDS", "AR_LANES_PER_WAVE", "AR_ALLOC_PER_ROUND", "AR_GROUPS", "AR_NO_ADVANCE_OVERLAP")
+knobs = ("AR_MLP_MT", "AR_GATHER_ROUNDS", "AR_LANES_PER_WAVE", "AR_ALLOC_PER_ROUND", "AR_GROUPS", "AR_NO_ADVANCE_OVERLAP")
 for rep in range(repeat):
     for cfg in configs:
         for k in knobs:
