@@ -189,3 +189,38 @@ def test_nn_eval_cache_skips_work_but_not_results():
                 np.testing.assert_array_equal(val, cached[i][key], err_msg=f"game {i} {key}")
             else:
                 assert val == cached[i][key], (i, key)
+
+
+def test_full_config_self_play_is_the_same_on_every_runtime_path(monkeypatch):
+    """BASELINE config 3 as the bench runs it (7x7, 1897 simulations, batch 16, tuned constants, noise, MLP
+    h256), 480 games on 160 lanes: trees outgrow their first arenas, slots are refilled, tree reuse runs on
+    the side stream. The same games on the plainest runtime path (no overflow pool -> host-grown arenas,
+    tree reuse in stream order) must give identical records."""
+    from alpharat_amd.sampling import rust_self_play
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        games = []
+        st = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=480, simulations=1897,
+                            batch_size=16, output_dir=None, seed=11, concurrent_games=160,
+                            weights_path=str(GOLD / "nets" / "mlp_7x7_h256.arnet"), c_puct=0.512, fpu_reduction=0.459,
+                            force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83, on_game=games.append)
+        for k in env:
+            monkeypatch.delenv(k)
+        return st, {g["game_index"]: g for g in games}
+
+    st_a, a = run()
+    st_b, b = run(AR_NO_POOL=1, AR_NO_ADVANCE_OVERLAP=1)
+    assert sorted(a) == sorted(b) == list(range(480))
+    assert st_a.total_simulations == st_b.total_simulations and st_a.total_nn_evals == st_b.total_nn_evals
+    for i, g in a.items():
+        for key, val in g.items():
+            if isinstance(val, np.ndarray):
+                np.testing.assert_array_equal(val, b[i][key], err_msg=f"game {i} {key}")
+            else:
+                assert val == b[i][key], (i, key)
+    # conservation + normalisation on every position
+    for g in a.values():
+        assert np.all(np.abs(g["policy_p1"].sum(axis=1) - 1) < 1e-5) and np.all(np.abs(g["policy_p2"].sum(axis=1) - 1) < 1e-5)
+        assert abs((g["cheese_outcomes"] != 2).sum() - (g["final_p1_score"] + g["final_p2_score"])) < 1e-6
