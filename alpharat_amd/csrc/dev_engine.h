@@ -30,13 +30,19 @@ struct State {
     uint8_t m1, m2;  // mud timers
 };
 
+// (the word is picked with selects, never a dynamic index: that would push the lane state into scratch memory)
 template <int NW>
 AR_HD bool st_has_cheese(const State<NW>& s, int cell) {
-    return (s.cheese[NW == 1 ? 0 : (cell >> 6)] >> (cell & 63)) & 1ULL;
+    uint64_t word = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) word |= (NW == 1 || (cell >> 6) == w) ? s.cheese[w] : 0ULL;
+    return (word >> (cell & 63)) & 1ULL;
 }
 template <int NW>
 AR_HD void st_take_cheese(State<NW>& s, int cell) {
-    s.cheese[NW == 1 ? 0 : (cell >> 6)] &= ~(1ULL << (cell & 63));
+    const uint64_t bit = 1ULL << (cell & 63);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s.cheese[w] &= (cell >> 6) == w ? ~bit : ~0ULL;
     s.remaining -= 1;
 }
 
