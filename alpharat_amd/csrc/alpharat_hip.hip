@@ -869,7 +869,7 @@ SearchCfg to_cfg(const ArSearchConfig& c, uint32_t sims, uint32_t batch) {
     s.coll_power = c.collision_scaling_power;
     s.n_sims = sims;
     s.batch_size = batch;
-    s.alloc_per_round = 2;  // measured best on the bench workload; results do not depend on it
+    s.alloc_per_round = 1;  // measured best on the bench workload; results do not depend on it
     if (const char* e = getenv("AR_ALLOC_PER_ROUND"))
         if (atoi(e) >= 1) s.alloc_per_round = (uint32_t)atoi(e);
     return s;
