@@ -479,27 +479,29 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp(NetDev net, const ar::LeafReq<
 // but the weights stream through once per block (K1 rows) instead of once per leaf (one row per set
 // feature), which is what bounded k_mlp: ~19 KB of L2 reads per leaf against ~2.4 KB here.
 // The operand x is generated in registers from the leaf's cells and cheese mask; nothing is staged.
-template <int MT, class AFn>
+// R = k-steps the weight loads run ahead of the MFMAs (register ring of 2 x 2R values): 8 covers the L2
+// latency when a SIMD holds several wavefronts (the MLP), the CNN's single wavefront per SIMD needs more
+template <int MT, int R = 8, class AFn>
 __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h, AFn a_of, f32x16 (&c)[MT][2]) {
     const float* bp1 = bp0 + (two ? 32 : 0);
-    float wa[8], wb[8], na[8], nb[8];
+    float wa[R], wb[R], na[R], nb[R];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int k = 2 * j;
         wa[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
         wb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
     }
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        if (k0 + 16 < K) {
+    for (int k0 = 0; k0 < K; k0 += 2 * R) {
+        if (k0 + 2 * R < K) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 16 + 2 * j;
+            for (int j = 0; j < R; ++j) {
+                const int k = k0 + 2 * R + 2 * j;
                 na[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
                 nb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < R; ++j) {
             const int k = k0 + 2 * j;
             if (k < K) {  // wave-uniform
 #pragma unroll
@@ -511,7 +513,7 @@ __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < R; ++j) {
             wa[j] = na[j];
             wb[j] = nb[j];
         }
@@ -585,7 +587,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
             for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
             return v;
         };
-        mfma_pass<MT>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, 3 * hw + 6, H, h, x_of, c);
+        mfma_pass<MT, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, 3 * hw + 6, H, h, x_of, c);
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -608,7 +610,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
             }
         const float* ap = act + (size_t)r * ld + h;
         auto a_of = [&](int k, int t) -> float { return ap[(size_t)(32 * t) * ld + k]; };
-        mfma_pass<MT>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_of, c);
+        mfma_pass<MT, 8>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_of, c);
     }
     __syncthreads();
     if (has) {

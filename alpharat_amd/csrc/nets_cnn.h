@@ -11,8 +11,8 @@
 // the rows) and one weight per tap from L2 (layout [ci][tap][co], coalesced over co).
 // BatchNorm that follows a convolution (stem_bn, bn2) is folded into it at load time; BatchNorm in
 // front of a ReLU on the residual stream (bn1, pool_bn) is a per-channel affine applied while the
-// padded copy is written. fp32 FMA throughout (f32 MFMA has the same peak on gfx950; moving these
-// loops onto v_mfma_f32_32x32x2_f32 is future work).
+// padded copy is written. The 3x3 convolutions run on v_mfma_f32_32x32x2_f32 when C is a multiple of 32
+// (conv3x3_tile_mfma), otherwise on fp32 FMA (conv3x3_tile); both give the same bits.
 #pragma once
 // (included from nets.h after the shared helpers)
 
@@ -95,6 +95,96 @@ __device__ inline void conv3x3_tile(const float* __restrict__ wt, const float* _
         }
 }
 
+// The same convolution on the matrix cores (C a multiple of 32): an implicit GEMM
+//   out[m = (leaf, y, x)][n = co] = bias[co] + sum_{k = ci * 9 + tap} in[leaf][ci][y + dy][x + dx] * w[k][co]
+// on v_mfma_f32_32x32x2_f32, whose accumulation is the k-ordered fmaf chain conv3x3_tile runs (ci outer,
+// taps inner, bias first), so the two produce the same bits. Wavefront w takes the 32 positions
+// 32w .. 32w+31 of the tile's CNN_TILE * hw (<= 128) and all output channels, 64 at a time (two accumulator
+// tiles share one read of the activations); the A operand is read straight from the zero-bordered LDS
+// image (no im2col), the weights stream from L2 through mfma_pass's register ring.
+template <typename Emit>
+__device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
+                                         const float* in, int in_leaf_stride, int h, int w, int tid, Emit emit) {
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
+    const int hw = h * w, M = CNN_TILE * hw, WP = w + 2, chs = (h + 2) * WP, K = Cin * 9;
+    if (wave * 32 >= M) return;  // wave-uniform
+    const int m = wave * 32 + r;
+    const bool row_ok = m < M;
+    const int mm = row_ok ? m : 0;
+    const float* a_row = in + (mm / hw) * in_leaf_stride + ((mm % hw) / w) * WP + (mm % hw) % w;
+    // k runs over (input channel, tap) two channels = 18 values = 9 MFMA steps at a time, so the tap of
+    // step p in lane half h2 is a compile-time pattern: k_local = 2p + h2 -> channel k_local / 9, tap k_local % 9
+    int off[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        const int kl = 2 * p + h2, cl = kl >= 9 ? 1 : 0, tap = kl - 9 * cl, dy = tap / 3, dx = tap - 3 * dy;
+        off[p] = cl * chs + dy * WP + dx;
+    }
+    const int n_pairs = (Cin + 1) / 2;
+    for (int n0 = 0; n0 < C; n0 += 64) {
+        const bool two = n0 + 32 < C;
+        const float* bp0 = wt + n0 + r;
+        const float* bp1 = bp0 + (two ? 32 : 0);
+        f32x16 c0, c1;
+        const float b0 = bias ? bias[n0 + r] : 0.0f, b1 = bias ? bias[n0 + (two ? 32 : 0) + r] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            c0[v] = b0;
+            c1[v] = b1;
+        }
+        // weights run DEPTH channel pairs (9 MFMA steps each) ahead of the multiplications, in a ring of
+        // DEPTH + 1 register buffers: with one wavefront per SIMD nothing else hides the L2 latency
+        constexpr int DEPTH = 3, RING = DEPTH + 1;
+        float wa[RING][9], wb[RING][9];
+        auto fetch = [&](int q, float* A9, float* B9) {
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                const int kk = q * 18 + 2 * p + h2;
+                A9[p] = kk < K ? bp0[(size_t)kk * C] : 0.0f;
+                B9[p] = kk < K ? bp1[(size_t)kk * C] : 0.0f;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if (u < n_pairs) fetch(u, wa[u], wb[u]);
+        for (int q0 = 0; q0 < n_pairs; q0 += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                const int q = q0 + u;
+                if (q < n_pairs) {  // wave-uniform
+                    if (q + DEPTH < n_pairs) fetch(q + DEPTH, wa[(u + DEPTH) % RING], wb[(u + DEPTH) % RING]);
+                    const float* ab = a_row + (size_t)(2 * q) * chs;
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) {
+                        if (q * 18 + 2 * p < K) {  // wave-uniform (false only in the second half of an odd last channel)
+                            const float a = (row_ok && q * 18 + 2 * p + h2 < K) ? ab[off[p]] : 0.0f;
+                            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[u][p], c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[u][p], c1, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int mo = wave * 32 + (v & 3) + 8 * (v >> 2) + 4 * h2;
+            if (mo < M) {
+                const int l = mo / hw, cell = mo % hw, y = cell / w, x = cell % w;
+                emit(l, n0 + r, y, x, c0[v]);
+                if (two) emit(l, n0 + 32 + r, y, x, c1[v]);
+            }
+        }
+    }
+}
+
+// scalar or matrix-core convolution by channel count (block-uniform)
+template <typename Emit>
+__device__ inline void conv3x3_any(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
+                                   const float* in, int in_leaf_stride, int h, int w, int tid, Emit emit) {
+    if ((C & 31) == 0 && CNN_TILE * h * w <= 32 * (NTHREADS / 64)) conv3x3_tile_mfma(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
+    else conv3x3_tile(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
+}
+
 template <int NW>
 __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
                                                   uint32_t n_fixed, const char* boards, size_t board_stride,
@@ -140,7 +230,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
     }
     __syncthreads();
     // stem: conv(5 -> C) + folded stem_bn + ReLU -> A
-    conv3x3_tile(net.stem_w, net.stem_b, 5, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+    conv3x3_any(net.stem_w, net.stem_b, 5, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
         A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x] = fmaxf(v, 0.0f);
     });
     __syncthreads();
@@ -154,6 +244,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
             for (int i = tid; i < L * G * hw; i += NTHREADS) {
                 const int l = i / (G * hw), rem = i % (G * hw), g = rem / hw, cell = rem % hw;
                 float acc = 0.0f;
+#pragma unroll 16  // the loads of 16 channels in flight together: the chain itself is only 16 fmas
                 for (int c = 0; c < C; ++c) {
                     const float xv = fmaxf(fmaf(blk.pbn_a[c], A[(size_t)l * a_leaf + (size_t)c * hw + cell], blk.pbn_b[c]), 0.0f);
                     acc = fmaf(blk.wp[(size_t)c * G + g], xv, acc);
@@ -177,6 +268,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
             for (int i = tid; i < L * C; i += NTHREADS) {
                 const int l = i / C, c = i % C;
                 float acc = blk.bl[c];
+#pragma unroll 16
                 for (int k = 0; k < 2 * G; ++k) acc = fmaf(blk.wl[(size_t)k * C + c], pcat[l * 2 * G + k], acc);
                 pout[l * C + c] = acc;
             }
@@ -185,6 +277,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
             __syncthreads();
         }
         // Bp = pad(relu(bn1(A)))
+#pragma unroll 4
         for (int i = tid; i < L * a_leaf; i += NTHREADS) {
             const int l = i / a_leaf, rem = i % a_leaf, c = rem / hw, cell = rem % hw;
             Bp[(size_t)l * p_leaf + (size_t)c * chs + (size_t)(cell / w + 1) * WP + (cell % w + 1)] =
@@ -192,12 +285,12 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         }
         __syncthreads();
         // Cp = pad(relu(conv1'(Bp)))   (bn2 folded)
-        conv3x3_tile(blk.w1, blk.b1, C, C, Bp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+        conv3x3_any(blk.w1, blk.b1, C, C, Bp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
             Cp[(size_t)l * p_leaf + (size_t)co * chs + (size_t)(y + 1) * WP + (x + 1)] = fmaxf(v, 0.0f);
         });
         __syncthreads();
         // A = conv2(Cp) [+ pooled] + A
-        conv3x3_tile(blk.w2, nullptr, C, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
+        conv3x3_any(blk.w2, nullptr, C, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
             float* a = &A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x];
             *a = blk.gpool ? v + pout[l * C + co] + *a : v + *a;
         });
@@ -231,6 +324,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         const int l = i / (2 * HD), rem = i % (2 * HD), p = rem / HD, o = rem % HD;
         const float* cv = cat + (size_t)(l * 2 + p) * (C + PD);
         float acc = net.cb_b[o];
+#pragma unroll 16
         for (int k = 0; k < C + PD; ++k) acc = fmaf(net.cb_w[(size_t)k * HD + o], cv[k], acc);
         hid[i] = fmaxf(acc, 0.0f);
     }
@@ -242,7 +336,9 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         const float* h1 = h0 + HD;
         const float* wr = net.hd_w + (size_t)o * 2 * HD;
         float acc = net.hd_b[o];
+#pragma unroll 16
         for (int k = 0; k < HD; ++k) acc = fmaf(wr[k], hi[k], acc);
+#pragma unroll 16
         for (int k = 0; k < HD; ++k) acc = fmaf(wr[HD + k], h0[k] + h1[k], acc);
         hl[i] = acc;
     }
