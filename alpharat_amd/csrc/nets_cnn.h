@@ -132,10 +132,11 @@ __device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const flo
             c0[v] = b0;
             c1[v] = b1;
         }
-        // weights run DEPTH channel pairs (9 MFMA steps each) ahead of the multiplications, in a ring of
-        // DEPTH + 1 register buffers: with one wavefront per SIMD nothing else hides the L2 latency
-        constexpr int DEPTH = 3, RING = DEPTH + 1;
-        float wa[RING][9], wb[RING][9];
+        // Weights of the next channel pair are fetched while this pair is multiplied. The nine steps of a
+        // pair are straight-line code: no guards inside (every branch there starts a new basic block with
+        // conservative s_waitcnt's in front of each MFMA). A step past K -- the second channel of an odd
+        // last pair -- gets zero weights and reads the next, finite, channel of the LDS image: it adds 0.
+        float wa[9], wb[9], na[9], nb[9];
         auto fetch = [&](int q, float* A9, float* B9) {
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
@@ -144,25 +145,22 @@ __device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const flo
                 B9[p] = kk < K ? bp1[(size_t)kk * C] : 0.0f;
             }
         };
+        fetch(0, wa, wb);
+        for (int q = 0; q < n_pairs; ++q) {
+            if (q + 1 < n_pairs) fetch(q + 1, na, nb);
+            const float* ab = a_row + (size_t)(2 * q) * chs;
+            float av[9];
 #pragma unroll
-        for (int u = 0; u < DEPTH; ++u)
-            if (u < n_pairs) fetch(u, wa[u], wb[u]);
-        for (int q0 = 0; q0 < n_pairs; q0 += RING) {
+            for (int p = 0; p < 9; ++p) av[p] = row_ok ? ab[off[p]] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < RING; ++u) {
-                const int q = q0 + u;
-                if (q < n_pairs) {  // wave-uniform
-                    if (q + DEPTH < n_pairs) fetch(q + DEPTH, wa[(u + DEPTH) % RING], wb[(u + DEPTH) % RING]);
-                    const float* ab = a_row + (size_t)(2 * q) * chs;
+            for (int p = 0; p < 9; ++p) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], wa[p], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], wb[p], c1, 0, 0, 0);
+            }
 #pragma unroll
-                    for (int p = 0; p < 9; ++p) {
-                        if (q * 18 + 2 * p < K) {  // wave-uniform (false only in the second half of an odd last channel)
-                            const float a = (row_ok && q * 18 + 2 * p + h2 < K) ? ab[off[p]] : 0.0f;
-                            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[u][p], c0, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[u][p], c1, 0, 0, 0);
-                        }
-                    }
-                }
+            for (int p = 0; p < 9; ++p) {
+                wa[p] = na[p];
+                wb[p] = nb[p];
             }
         }
 #pragma unroll
@@ -185,6 +183,12 @@ __device__ inline void conv3x3_any(const float* __restrict__ wt, const float* __
     else conv3x3_tile(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
 }
 
+#if defined(AR_CNN_PROF)
+__device__ int g_cnn_prof_done = 0;
+#define CNN_T(i) do { __syncthreads(); if (prof) tp[i] = wall_clock64(); } while (0)
+#else
+#define CNN_T(i) ((void)0)
+#endif
 template <int NW>
 __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
                                                   uint32_t n_fixed, const char* boards, size_t board_stride,
@@ -204,6 +208,13 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
     if (base >= n) return;
     const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
     const int tid = threadIdx.x;
+#if defined(AR_CNN_PROF)
+    const bool prof = blockIdx.x == 0 && tid == 0;
+    unsigned long long tp[24];
+    for (int i = 0; i < 24; ++i) tp[i] = 0;
+    int tpi = 0;
+#endif
+    CNN_T(0);
     // zero both padded buffers once: borders stay zero, interiors are always overwritten
     for (int i = tid; i < 2 * L * p_leaf; i += NTHREADS) Bp[i] = 0.0f;
     if (tid < L) {
@@ -229,11 +240,13 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         Cp[(size_t)l * p_leaf + (size_t)c * chs + (size_t)(cell / w + 1) * WP + (cell % w + 1)] = v;
     }
     __syncthreads();
+    CNN_T(1);
     // stem: conv(5 -> C) + folded stem_bn + ReLU -> A
     conv3x3_any(net.stem_w, net.stem_b, 5, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
         A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x] = fmaxf(v, 0.0f);
     });
     __syncthreads();
+    CNN_T(2);
     for (int bi = 0; bi < net.n_blocks; ++bi) {
         const CnnBlockDev& blk = net.blk[bi];
         float* pout = small;  // [L][C] pooled-branch output (gpool blocks)
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
             for (int i = tid; i < L * p_leaf; i += NTHREADS) Cp[i] = 0.0f;  // restore the zero borders
             __syncthreads();
         }
+        CNN_T(3 + bi * 4);
         // Bp = pad(relu(bn1(A)))
 #pragma unroll 4
         for (int i = tid; i < L * a_leaf; i += NTHREADS) {
@@ -284,17 +298,20 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
                 fmaxf(fmaf(blk.bn1_a[c], A[i], blk.bn1_b[c]), 0.0f);
         }
         __syncthreads();
+        CNN_T(4 + bi * 4);
         // Cp = pad(relu(conv1'(Bp)))   (bn2 folded)
         conv3x3_any(blk.w1, blk.b1, C, C, Bp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
             Cp[(size_t)l * p_leaf + (size_t)co * chs + (size_t)(y + 1) * WP + (x + 1)] = fmaxf(v, 0.0f);
         });
         __syncthreads();
+        CNN_T(5 + bi * 4);
         // A = conv2(Cp) [+ pooled] + A
         conv3x3_any(blk.w2, nullptr, C, C, Cp, p_leaf, h, w, tid, [&](int l, int co, int y, int x, float v) {
             float* a = &A[(size_t)l * a_leaf + (size_t)co * hw + y * w + x];
             *a = blk.gpool ? v + pout[l * C + co] + *a : v + *a;
         });
         __syncthreads();
+        CNN_T(6 + bi * 4);
     }
     // heads: features at the player cells, player encoder, combiner, DeepSet heads
     const int PD = net.PD, HD = net.HD;
@@ -343,6 +360,17 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         hl[i] = acc;
     }
     __syncthreads();
+    CNN_T(20);
+#if defined(AR_CNN_PROF)
+    if (prof && atomicCAS(&g_cnn_prof_done, 0, 1) == 0) {
+        printf("[cnn prof, 10 ns ticks] zero+input %llu stem %llu", tp[1] - tp[0], tp[2] - tp[1]);
+        for (int bi = 0; bi < net.n_blocks; ++bi)
+            printf(" | blk%d pool %llu bn %llu conv1 %llu conv2 %llu", bi, tp[3 + bi * 4] - (bi ? tp[2 + bi * 4] : tp[2]),
+                   tp[4 + bi * 4] - tp[3 + bi * 4], tp[5 + bi * 4] - tp[4 + bi * 4], tp[6 + bi * 4] - tp[5 + bi * 4]);
+        printf(" | heads %llu\n", tp[20] - tp[2 + net.n_blocks * 4]);
+    }
+    (void)tpi;
+#endif
     if (tid < cnt) {
         const float* hh = hl + tid * 12;
         ar::EvalOut o;
