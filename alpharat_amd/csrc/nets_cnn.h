@@ -136,7 +136,10 @@ __device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const flo
         // pair are straight-line code: no guards inside (every branch there starts a new basic block with
         // conservative s_waitcnt's in front of each MFMA). A step past K -- the second channel of an odd
         // last pair -- gets zero weights and reads the next, finite, channel of the LDS image: it adds 0.
-        float wa[9], wb[9], na[9], nb[9];
+        // three register buffers in rotation: while pair q is multiplied the weights of q + 1 are (mostly)
+        // there and those of q + 2 are on their way -- two pairs (2 x 9 MFMA steps) of distance to the L2.
+        // A fetch past the last pair touches no memory (all its k are >= K) and yields zeros.
+        float w0a[9], w0b[9], w1a[9], w1b[9], w2a[9], w2b[9];
         auto fetch = [&](int q, float* A9, float* B9) {
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
@@ -145,22 +148,29 @@ __device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const flo
                 B9[p] = kk < K ? bp1[(size_t)kk * C] : 0.0f;
             }
         };
-        fetch(0, wa, wb);
-        for (int q = 0; q < n_pairs; ++q) {
-            if (q + 1 < n_pairs) fetch(q + 1, na, nb);
+        auto multiply = [&](int q, const float* A9, const float* B9) {
             const float* ab = a_row + (size_t)(2 * q) * chs;
             float av[9];
 #pragma unroll
             for (int p = 0; p < 9; ++p) av[p] = row_ok ? ab[off[p]] : 0.0f;
 #pragma unroll
             for (int p = 0; p < 9; ++p) {
-                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], wa[p], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], wb[p], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], A9[p], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], B9[p], c1, 0, 0, 0);
             }
-#pragma unroll
-            for (int p = 0; p < 9; ++p) {
-                wa[p] = na[p];
-                wb[p] = nb[p];
+        };
+        fetch(0, w0a, w0b);
+        fetch(1, w1a, w1b);
+        for (int q = 0; q < n_pairs; q += 3) {
+            fetch(q + 2, w2a, w2b);
+            multiply(q, w0a, w0b);
+            if (q + 1 < n_pairs) {
+                fetch(q + 3, w0a, w0b);
+                multiply(q + 1, w1a, w1b);
+            }
+            if (q + 2 < n_pairs) {
+                fetch(q + 4, w1a, w1b);
+                multiply(q + 2, w2a, w2b);
             }
         }
 #pragma unroll
