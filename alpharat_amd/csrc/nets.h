@@ -491,31 +491,42 @@ __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h
         wa[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
         wb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
     }
-    for (int k0 = 0; k0 < K; k0 += 2 * R) {
-        if (k0 + 2 * R < K) {
+    // whole chunks of R steps are straight-line code (a guard per step would start a new basic block, and
+    // with it conservative s_waitcnt's, in front of every MFMA); only the last, partial chunk is guarded
+    const int K_main = K - K % (2 * R);
+    int k0 = 0;
+    for (; k0 < K_main; k0 += 2 * R) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const int k = k0 + 2 * R + 2 * j;
-                na[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
-                nb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
-            }
+        for (int j = 0; j < R; ++j) {  // next chunk (a load past K yields 0 without touching memory)
+            const int k = k0 + 2 * R + 2 * j;
+            na[j] = k + h < K ? bp0[(size_t)k * H] : 0.0f;
+            nb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const int k = k0 + 2 * j;
-            if (k < K) {  // wave-uniform
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const float a = a_of(k, t);
-                    c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c[t][0], 0, 0, 0);
-                    c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c[t][1], 0, 0, 0);
-                }
+            for (int t = 0; t < MT; ++t) {
+                const float a = a_of(k0 + 2 * j, t);
+                c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c[t][0], 0, 0, 0);
+                c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c[t][1], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             wa[j] = na[j];
             wb[j] = nb[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int k = k0 + 2 * j;
+        if (k < K) {  // wave-uniform
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float a = a_of(k, t);
+                c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c[t][0], 0, 0, 0);
+                c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c[t][1], 0, 0, 0);
+            }
         }
     }
 }
