@@ -117,6 +117,9 @@ EXPORTS = {
     "ar_version": (C.c_char_p, []),
     "ar_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "ar_device_count": (C.c_int, []),
+    "ar_generate_maze": (C.c_int, [C.c_uint8, C.c_uint8, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_void_p]),
+    "ar_generate_cheese": (C.c_int, [C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int, C.c_uint64,
+                                    C.c_void_p]),
     "ar_device_sync": (C.c_int, [C.c_int]),
     "ar_release_device_memory": (C.c_int, [C.c_int]),
     "ar_net_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

@@ -2150,6 +2150,28 @@ int ar_device_count(void) {
     return n;
 }
 
+// ---- game generation, host only (no device needed): what ar_selfplay_run draws for game `seed` ----------
+int ar_generate_maze(uint8_t width, uint8_t height, float wall_density, float mud_density, int symmetric, uint64_t seed,
+                     uint8_t* cost_out) {
+    if (!cost_out || width == 0 || height == 0 || (int)width * height > 256) return fail(AR_E_INVALID, "bad board");
+    const std::vector<uint8_t> c = generate_maze(width, height, wall_density, mud_density, symmetric != 0, seed);
+    memcpy(cost_out, c.data(), c.size());
+    return AR_OK;
+}
+int ar_generate_cheese(uint8_t width, uint8_t height, uint8_t p1_cell, uint8_t p2_cell, uint16_t count, int symmetric,
+                       uint64_t seed, uint8_t* cheese_out) {
+    if (!cheese_out || width == 0 || height == 0 || (int)width * height > 256) return fail(AR_E_INVALID, "bad board");
+    HostGame g;
+    g.width = width;
+    g.height = height;
+    g.p1 = p1_cell;
+    g.p2 = p2_cell;
+    std::string err;
+    if (!place_cheese(g, count, symmetric != 0, seed, err)) return fail(AR_E_INVALID, err);
+    memcpy(cheese_out, g.cheese.data(), g.cheese.size());
+    return AR_OK;
+}
+
 #if defined(AR_STATS)
 int ar_debug_round_stats(unsigned long long* out32) {
     HIP_TRY(hipDeviceSynchronize());

@@ -89,6 +89,15 @@ const char* ar_version(void);
 size_t ar_last_error(char* buf, size_t cap);
 /* number of visible HIP devices, or AR_E_DEVICE */
 int ar_device_count(void);
+/* Game generation, host only (works without a device): the walls + mud (`cost_out[cells * 4]`: 0 wall / edge,
+ * 1 open, >= 2 mud; directions UP RIGHT DOWN LEFT) and the cheese mask (`cheese_out[cells]`) that
+ * ar_selfplay_run draws for the game seeded `seed` (= game_seed_base + game index). The reference leaves
+ * both to the pyrat-rust engine (bindings.rs:502-532), which is not available: own generators, DESIGN.md
+ * "game generation". Player cells are y * width + x. */
+int ar_generate_maze(uint8_t width, uint8_t height, float wall_density, float mud_density, int symmetric, uint64_t seed,
+                     uint8_t* cost_out);
+int ar_generate_cheese(uint8_t width, uint8_t height, uint8_t p1_cell, uint8_t p2_cell, uint16_t count, int symmetric,
+                       uint64_t seed, uint8_t* cheese_out);
 /* hipDeviceSynchronize on `device` (benchmark bracketing) */
 int ar_device_sync(int device);
 /* The library keeps one tree-arena allocation per device between calls (the driver clears device

@@ -54,3 +54,34 @@ def test_generated_maze_depends_on_seed_only():
     c = O.Game(7, 7, 50).random_maze(0.7, 0.1, True, 4).cost()
     assert (a == b).all() and (a != c).any()
     assert (O.Game(7, 7, 50).random_maze(0.0, 0.0, True, 1).cost() == O.Game(7, 7, 50).cost()).all()  # densities 0: open
+
+
+# ---- the product's own implementations of the two generators, through the C-ABI (host only: no GPU needed) ----
+def _lib():
+    from alpharat_amd import _lib as L
+
+    return L, L.load()
+
+
+@pytest.mark.parametrize("w,h", [(5, 5), (7, 7), (7, 5), (15, 11), (16, 16)])
+def test_product_maze_generator_equals_the_oracles(w, h):
+    L, lib = _lib()
+    rng = np.random.default_rng(w * 100 + h)
+    for seed in list(range(40)) + [2**63 + 5, 2**64 - 1]:
+        wd, md, sym = float(np.float32(rng.random())), float(np.float32(rng.random() * 0.5)), bool(rng.integers(0, 2))
+        got = np.zeros((h, w, 4), np.uint8)
+        L.check(lib.ar_generate_maze(w, h, wd, md, int(sym), seed, got.ctypes.data))
+        want = O.Game(w, h, 50).random_maze(wd, md, sym, seed).cost()
+        np.testing.assert_array_equal(got, want, err_msg=f"seed {seed} wd {wd} md {md} sym {sym}")
+
+
+@pytest.mark.parametrize("w,h,count", [(5, 5, 5), (7, 7, 10), (7, 7, 9), (15, 11, 21), (7, 5, 6)])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_product_cheese_sampler_equals_the_oracles(w, h, count, symmetric):
+    L, lib = _lib()
+    for seed in range(60):
+        got = np.zeros(w * h, np.uint8)
+        L.check(lib.ar_generate_cheese(w, h, 0, w * h - 1, count, int(symmetric), seed, got.ctypes.data))
+        g = O.Game(w, h, 50).random_cheese(count, symmetric, seed)
+        assert got.sum() == count
+        np.testing.assert_array_equal(got, g.cheese_mask(), err_msg=f"seed {seed}")
