@@ -133,6 +133,10 @@ EXPORTS = {
                                  C.POINTER(C.c_uint64), C.c_void_p, C.c_int, C.POINTER(ArSearchResult)]),
     "ar_selfplay_run": (C.c_int, [C.POINTER(ArSelfPlayParams), C.POINTER(ArProgress), ArGameSink, C.c_void_p,
                                   C.POINTER(ArSelfPlayStats)]),
+    "ar_selfplay_open": (C.c_int, [C.POINTER(ArSelfPlayParams), C.POINTER(ArProgress), ArGameSink, C.c_void_p,
+                                   C.POINTER(C.c_void_p)]),
+    "ar_selfplay_step": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(ArSelfPlayStats), C.POINTER(C.c_int)]),
+    "ar_selfplay_close": (C.c_int, [C.c_void_p, C.POINTER(ArSelfPlayStats)]),
     "ar_write_bundle": (C.c_int, [C.POINTER(ArGameRecordView), C.c_uint32, C.c_char_p]),
 }
 

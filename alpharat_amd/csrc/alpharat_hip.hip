@@ -451,21 +451,48 @@ __global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots, Bases B) {
     slots[i] = s;
 }
 
-// counts[0] done, [1] stalled, [2] active (incl. waiting for k_advance), [3] errors; lists hold slot ids
+// counts[0] done, [1] stalled, [2] active (incl. waiting for k_advance), [3] errors; lists hold slot ids.
+// live[0..9): sums over the games that sit in a slot right now (finished-but-not-drained ones included) of
+// positions, simulations, nn evals, terminals, collisions, gather / backup node-visits, new nodes, and the
+// number of such games -- the host adds them to the totals of the games already drained, so a session can
+// report the work done inside a window of steps (per finished move) without waiting for games to end.
+enum { LIVE_N = 9 };
 template <int NW>
 __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts, uint32_t* done_list,
-                       uint32_t* stall_list, uint32_t* release_list, ArenaPool P) {
+                       uint32_t* stall_list, uint32_t* release_list, ArenaPool P, unsigned long long* live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
+    const bool in = i < n_slots;
     if (i == 0 && P.top)  // free overflow blocks per class, for the host's bookkeeping
         for (int c = 0; c < POOL_CLASSES; ++c) counts[5 + c] = (uint32_t)(P.top[c] > 0 ? P.top[c] : 0);
-    const uint32_t st = slots[i].status;
-    if (slots[i].error) atomicAdd(&counts[3], 1u);
-    if (slots[i].release_grown) release_list[atomicAdd(&counts[4], 1u)] = i;
-    if (st == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
-    else if (st == SLOT_STALL || st == SLOT_STALL_B) stall_list[atomicAdd(&counts[1], 1u)] = i;
-    else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE || st == SLOT_ADVANCE_B || st == SLOT_READY_A || st == SLOT_READY_B)
-        atomicAdd(&counts[2], 1u);
+    unsigned long long v[LIVE_N];
+    for (int k = 0; k < LIVE_N; ++k) v[k] = 0;
+    if (in) {
+        const Slot<NW>& s = slots[i];
+        const uint32_t st = s.status;
+        if (s.error) atomicAdd(&counts[3], 1u);
+        if (s.release_grown) release_list[atomicAdd(&counts[4], 1u)] = i;
+        if (st == SLOT_DONE) done_list[atomicAdd(&counts[0], 1u)] = i;
+        else if (st == SLOT_STALL || st == SLOT_STALL_B) stall_list[atomicAdd(&counts[1], 1u)] = i;
+        else if (st == SLOT_ACTIVE || st == SLOT_ADVANCE || st == SLOT_ADVANCE_B || st == SLOT_READY_A || st == SLOT_READY_B)
+            atomicAdd(&counts[2], 1u);
+        if (st != SLOT_EMPTY && live != nullptr) {
+            v[0] = s.n_pos;
+            v[1] = s.t_sims;
+            v[2] = s.t_nn;
+            v[3] = s.t_term;
+            v[4] = s.t_coll;
+            v[5] = s.nv_gather;
+            v[6] = s.nv_backup;
+            v[7] = s.new_nodes;
+            v[8] = 1;
+        }
+    }
+    if (live == nullptr) return;
+    for (int k = 0; k < LIVE_N; ++k) {  // one atomic per wavefront and counter
+        unsigned long long x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x += (unsigned long long)__shfl_xor((long long)x, off, 64);
+        if ((threadIdx.x & 63u) == 0 && x) atomicAdd(&live[k], x);
+    }
 }
 
 // one block per finished game: header by thread 0, position records copied by the whole block
@@ -555,17 +582,22 @@ __global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n, Ba
 //     get their result at once, misses are compacted into a second queue for the network;
 //   k_cache_fill:  results of the misses go to their place in the batch and into the table (first empty
 //     slot of the probe window, else the home slot is overwritten). Writers claim a slot by CAS on its
-//     tag; readers only run in k_cache_probe, i.e. after a kernel boundary, and never see a slot mid-write.
+//     tag; readers only run in k_cache_probe, i.e. after a kernel boundary, and never see a slot mid-write
+//     (the cache forces one group of games: one probe / fill pair in flight at a time).
+// The maze is part of the key like in the reference (walls and mud are hashed, cached_backend.rs:130-199):
+// with one shared maze the key is its pool offset; with generated mazes (one pool entry per slot, rewritten
+// for every new game) it is the game the position belongs to -- only that game has that maze.
 enum { CACHE_PROBES = 8, CACHE_EMPTY = 0, CACHE_VALID = 1, CACHE_BUSY = 2 };
 template <int NW>
 struct alignas(16) CacheEntry {
     State<NW> st;
     uint32_t maze_off;
     uint32_t tag;
+    uint32_t maze_game;  // 0: shared maze; game index + 1 with one maze per game
     EvalOut ev;
 };
 template <int NW>
-__device__ inline uint64_t position_hash(const State<NW>& st, uint32_t maze_off) {  // FNV-1a, cached_backend.rs:135-199
+__device__ inline uint64_t position_hash(const State<NW>& st, uint32_t maze_off, uint32_t maze_game) {  // FNV-1a, cached_backend.rs:135-199
     uint64_t h = 0xcbf29ce484222325ULL;
     auto mix = [&](uint64_t v) {
         h ^= v;
@@ -579,6 +611,7 @@ __device__ inline uint64_t position_hash(const State<NW>& st, uint32_t maze_off)
     mix(st.m2);
     mix(st.turn);
     mix(maze_off);
+    mix(maze_game);
     for (int w = 0; w < NW; ++w) mix(st.cheese[w]);
     return h;
 }
@@ -592,18 +625,20 @@ __device__ inline bool same_position(const State<NW>& a, const State<NW>& b) {
 template <int NW>
 __global__ void k_cache_probe(const LeafReq<NW>* queue, const uint32_t* n_ptr, const Slot<NW>* slots,
                               const CacheEntry<NW>* table, uint64_t mask, EvalOut* ev_out, LeafReq<NW>* miss_queue,
-                              uint32_t* miss_map, uint32_t* miss_count, unsigned long long* counters) {
+                              uint32_t* miss_map, uint32_t* miss_count, unsigned long long* counters,
+                              uint32_t maze_per_game) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < *n_ptr;
     LeafReq<NW> r = queue[in ? i : 0];
     bool hit = false;
     if (in) {
         const uint32_t maze_off = slots[r.slot].board.maze_off;
-        const uint64_t h = position_hash(r.st, maze_off);
+        const uint32_t maze_game = maze_per_game ? slots[r.slot].game_index + 1u : 0u;
+        const uint64_t h = position_hash(r.st, maze_off, maze_game);
         for (int p = 0; p < CACHE_PROBES && !hit; ++p) {
             const CacheEntry<NW>& e = table[(h + (uint64_t)p) & mask];
             if (e.tag == CACHE_EMPTY) break;
-            if (e.tag == CACHE_VALID && e.maze_off == maze_off && same_position(e.st, r.st)) {
+            if (e.tag == CACHE_VALID && e.maze_off == maze_off && e.maze_game == maze_game && same_position(e.st, r.st)) {
                 ev_out[i] = e.ev;
                 hit = true;
             }
@@ -630,14 +665,15 @@ __global__ void k_cache_probe(const LeafReq<NW>* queue, const uint32_t* n_ptr, c
 template <int NW>
 __global__ void k_cache_fill(const LeafReq<NW>* miss_queue, const uint32_t* miss_map, const uint32_t* miss_count,
                              const EvalOut* ev_miss, const Slot<NW>* slots, CacheEntry<NW>* table, uint64_t mask,
-                             EvalOut* ev_out) {
+                             EvalOut* ev_out, uint32_t maze_per_game) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= *miss_count) return;
     const LeafReq<NW> r = miss_queue[j];
     const EvalOut ev = ev_miss[j];
     ev_out[miss_map[j]] = ev;
     const uint32_t maze_off = slots[r.slot].board.maze_off;
-    const uint64_t h = position_hash(r.st, maze_off);
+    const uint32_t maze_game = maze_per_game ? slots[r.slot].game_index + 1u : 0u;
+    const uint64_t h = position_hash(r.st, maze_off, maze_game);
     // first empty slot of the window; a position that is already there (or being written by a twin in
     // this batch) is left alone; a full window overwrites the home slot
     for (int p = 0; p <= CACHE_PROBES; ++p) {
@@ -645,7 +681,7 @@ __global__ void k_cache_fill(const LeafReq<NW>* miss_queue, const uint32_t* miss
         CacheEntry<NW>& e = table[(h + (uint64_t)(evict ? 0 : p)) & mask];
         const uint32_t tag = e.tag;
         if (!evict && tag == CACHE_VALID) {
-            if (e.maze_off == maze_off && same_position(e.st, r.st)) return;
+            if (e.maze_off == maze_off && e.maze_game == maze_game && same_position(e.st, r.st)) return;
             continue;
         }
         if (!evict && tag == CACHE_BUSY) continue;
@@ -656,6 +692,7 @@ __global__ void k_cache_fill(const LeafReq<NW>* miss_queue, const uint32_t* miss
         }
         e.st = r.st;
         e.maze_off = maze_off;
+        e.maze_game = maze_game;
         e.ev = ev;
         __threadfence();
         atomicExch(&e.tag, (uint32_t)CACHE_VALID);
@@ -1046,6 +1083,8 @@ struct Engine {
     DevBuf<EvalOut> ev_queue;
     DevBuf<uint32_t> queue_count;
     PinBuf<uint32_t> h_counts, h_release;
+    DevBuf<unsigned long long> live;  // k_scan's sums over the resident games (LIVE_N values)
+    PinBuf<unsigned long long> h_live;
     PinBuf<StallInfo> h_stall;
     PinBuf<DoneInfo<NW>> h_info;
     PinBuf<PosRec<NW>> h_staging;
@@ -1076,7 +1115,7 @@ struct Engine {
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
     DevBuf<int> pool_ctr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;  // ev_order: side streams start after the main stream's refills
     double device_ms = 0.0;
     uint64_t steps = 0;
     uint64_t grows = 0;
@@ -1106,6 +1145,7 @@ struct Engine {
         for (hipEvent_t e : gather_ev) hipEventDestroy(e);
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
+        if (ev_order) hipEventDestroy(ev_order);
         if (stream) hipStreamDestroy(stream);
     }
 
@@ -1139,6 +1179,7 @@ struct Engine {
         HIP_TRY(hipStreamCreate(&stream));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventCreateWithFlags(&ev_order, hipEventDisableTiming));
         L = make_layout<NW>(cfg, max_turns);
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
@@ -1198,6 +1239,8 @@ struct Engine {
         HIP_TRY(staging.alloc((size_t)S * max_turns));
         HIP_TRY(grow.alloc(S));
         HIP_TRY(h_counts.alloc(8));
+        HIP_TRY(live.alloc(16));
+        HIP_TRY(h_live.alloc(16));
         HIP_TRY(h_stall.alloc(S));
         HIP_TRY(h_info.alloc(S));
         HIP_TRY(h_staging.alloc((size_t)S * max_turns));
@@ -1333,10 +1376,10 @@ struct Engine {
             uint32_t* mc = miss_count.p + gi;
             HIP_TRY(hipMemsetAsync(mc, 0, 4, g.stream));
             hipLaunchKernelGGL(k_cache_probe<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, q, qc, slots.p,
-                               cache_table.p, cache_entries - 1, ev, mq, mm, mc, cache_counters.p);
+                               cache_table.p, cache_entries - 1, ev, mq, mm, mc, cache_counters.p, per_slot_maze ? 1u : 0u);
             if (int rc = net_forward_queue<NW>(net, mq, mc, n_max, slots.p, maze.p, em, g.stream)) return rc;
             hipLaunchKernelGGL(k_cache_fill<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, mq, mm, mc, em, slots.p,
-                               cache_table.p, cache_entries - 1, ev);
+                               cache_table.p, cache_entries - 1, ev, per_slot_maze ? 1u : 0u);
         } else if (int rc = net_forward_queue<NW>(net, q, qc, n_max, slots.p, maze.p, ev, g.stream)) {
             return rc;
         }
@@ -1373,7 +1416,7 @@ struct Engine {
     // `n_launch` rounds of {`iters` simulate_batch per game, then tree reuse for the games that moved},
     // timed with HIP events on our stream
     int run_steps(int n_launch, int iters) {
-        HIP_TRY(hipEventRecord(ev0, stream));
+        if (!timed) HIP_TRY(hipEventRecord(ev0, stream));  // several calls between two scans are timed as one interval
         for (int k = 0; k < n_launch; ++k) {
             if (net == nullptr) {
                 hipLaunchKernelGGL(k_step_uniform<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
@@ -1388,9 +1431,10 @@ struct Engine {
             if (groups.empty())
                 if (int rc = make_groups(1)) return rc;
             const bool multi = groups.size() > 1;
+            HIP_TRY(hipEventRecord(ev_order, stream));
             for (const Group& g : groups) {
-                if (multi) HIP_TRY(hipStreamWaitEvent(g.stream, ev0, 0));
-                if (g.adv_stream) HIP_TRY(hipStreamWaitEvent(g.adv_stream, ev0, 0));
+                if (multi) HIP_TRY(hipStreamWaitEvent(g.stream, ev_order, 0));
+                if (g.adv_stream) HIP_TRY(hipStreamWaitEvent(g.adv_stream, ev_order, 0));
             }
             for (int k = 0; k < n_launch * iters; ++k)
                 for (Group& g : groups)
@@ -1416,10 +1460,12 @@ struct Engine {
     int scan(uint32_t out_counts[4]) {
         if (pool.top) hipLaunchKernelGGL(k_pool_merge, dim3(POOL_CLASSES), dim3(256), 0, stream, pool);
         HIP_TRY(hipMemsetAsync(counts.p, 0, 32, stream));
+        HIP_TRY(hipMemsetAsync(live.p, 0, 8 * LIVE_N, stream));
         hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
-                           stall_list.p, release_list.p, pool);
+                           stall_list.p, release_list.p, pool, live.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 32, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_live.p, live.p, 8 * LIVE_N, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (const uint32_t n_rel = h_counts.p[4]) {  // slots that moved back to their pool share
             HIP_TRY(hipMemcpyAsync(h_release.p, release_list.p, 4 * n_rel, hipMemcpyDeviceToHost, stream));
@@ -1702,29 +1748,51 @@ int parse_device(const char* device, int device_index, int& out) {
 // descent is one round per tree level) and cuts the long tail; measured in DESIGN.md section 7.
 static uint32_t default_gather_rounds(const SearchCfg&) { return 0xFFFFFFFFu; }
 
+// A self-play run as an object that outlives one call: the engine, its resident games and the supply of
+// new games stay alive between ar_selfplay_step calls, so a caller can run the sampler in bounded slices
+// (the benchmark's "step") or to the end (ar_selfplay_run = open + step until finished + close).
+// The counterpart in the reference is the worker pool of run_self_play_to_disk (selfplay.rs:721-808), which
+// lives for one call only; the slicing is an extension.
+struct SessionBase {
+    virtual ~SessionBase() {}
+    virtual int step(uint32_t batch_steps, ArSelfPlayStats* window, int* finished_out) = 0;
+    virtual int close(ArSelfPlayStats* total) = 0;
+};
+
 template <int NW>
-int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress* progress, ArGameSink sink,
-                  void* sink_user, ArSelfPlayStats* out) {
-    SearchCfg cfg = to_cfg(p.search, p.simulations, p.batch_size);
-    if (int rc = check_cfg(cfg)) return rc;
-    const std::vector<uint8_t> cost = open_maze_cost(p.width, p.height);
-    const int hw = p.width * p.height;
+struct SelfPlaySession : SessionBase {
+    ArSelfPlayParams p;  // strings are copied below; the pointers in here are not used after open()
+    SearchCfg cfg;
+    std::vector<uint8_t> cost;
+    int hw = 0;
+    uint64_t gseed = 0, rseed = 0;
+    bool random_pos = false, gen_maze = false, maze_sym = true, unbounded = false;
+    float wall_d = 0.0f, mud_d = 0.0f;
+    uint32_t S = 0;
+    Engine<NW> eng;
+    ArNet* net = nullptr;  // owned by the ArSelfPlaySession wrapper (freed after the engine)
+    BundleSink writer;
+    bool to_disk = false;
+    ArProgress* progress = nullptr;
+    ArGameSink sink = nullptr;
+    void* sink_user = nullptr;
+    ArSelfPlayStats st;  // finished games
+    unsigned long long live[LIVE_N] = {0};  // resident games at the last scan, minus the ones drained since
+    std::vector<HostGame> slot_game;
+    uint64_t next_game = 0, finished = 0;
+    std::chrono::steady_clock::time_point t0;
+    std::string err;
+    bool timing = false, failed = false;
+    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    uint64_t gseed = p.game_seed_base, rseed = p.rng_seed_base;
-    if (!p.has_seed) {  // reference behaviour: entropy (selfplay.rs:622, bindings.rs:530-532)
-        std::random_device rd;
-        gseed = ((uint64_t)rd() << 32) | rd();
-        rseed = ((uint64_t)rd() << 32) | rd();
+    ~SelfPlaySession() override {
+        if (to_disk) writer.finish();
+        if (eng.stream) hipStreamSynchronize(eng.stream);
+        // the evaluator outlives every kernel that reads its weights: ~Engine synchronises its streams, so
+        // the engine has to go first -- done explicitly in close(); here only as a last resort
     }
-    const bool random_pos = p.positions && std::string(p.positions) == "random";
-    // "classic" = the engine's default walls and mud (bindings.rs:507 with_classic_maze; taken here as density
-    // 0.7 / 0.1, symmetric -- the defaults of the binding's own signature), "random" = the caller's parameters
-    const std::string maze_type = p.maze_type ? p.maze_type : "open";
-    const bool gen_maze = maze_type != "open";
-    const float wall_d = maze_type == "classic" ? 0.7f : p.wall_density, mud_d = maze_type == "classic" ? 0.1f : p.mud_density;
-    const bool maze_sym = maze_type == "classic" ? true : p.maze_symmetric != 0;
 
-    auto make_game = [&](uint32_t index, HostGame& g, std::string& err) -> bool {
+    bool make_game(uint32_t index, HostGame& g) {
         if (gen_maze) g.cost = generate_maze(p.width, p.height, wall_d, mud_d, maze_sym, gseed + index);
         g.width = p.width;
         g.height = p.height;
@@ -1741,98 +1809,19 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
             if (!p.cheese_symmetric) g.p2 = (uint8_t)rng.below((uint32_t)hw);
         }
         return place_cheese(g, p.cheese_count, p.cheese_symmetric != 0, gseed + index, err);
-    };
-
-    // resident games: bounded by the request, the caller's hint and the arena footprint
-    uint32_t S = p.concurrent_games ? p.concurrent_games : 16384;
-    if (S > p.num_games) S = p.num_games;
-    size_t pool_bytes = 0;
-    const uint32_t arena_nodes = getenv("AR_ARENA_NODES") ? (uint32_t)atoi(getenv("AR_ARENA_NODES")) : 0u;  // test knob
-    if (S == 0) {
-        memset(out, 0, sizeof *out);
-        return AR_OK;
-    }
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipSetDevice(device) != hipSuccess) return fail(AR_E_DEVICE, "hipSetDevice failed");
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        free_b += arena_cached_bytes(device);  // the block kept from the previous call is ours to reuse
-        const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
-                                Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr);
-        const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
-        if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
-        if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
-        // the overflow pool gets what is left, minus a reserve for the evaluator's buffers and the
-        // (rare) arenas beyond the largest pool class, which the host allocates one by one
-        const size_t reserve = (size_t)4 << 30;
-        const size_t used = (size_t)S * per_game;
-        pool_bytes = free_b > used + reserve ? (free_b - used - reserve) / 100 * 85 : 0;
     }
 
-    // AR_TIMING=1 prints where the host wall time of this call went (stderr)
-    const bool timing = getenv("AR_TIMING") != nullptr;
-    double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(now() - a).count(); };
-    auto tp = now();
+    bool supply_left() const { return unbounded || next_game < p.num_games; }
+    bool all_finished() const { return !unbounded && finished >= p.num_games; }
 
-    Engine<NW> eng;
-    eng.net = net;
-    if (p.cache_size && net != nullptr) {
-        // the reference sizes one table per worker thread (capacity x 1.9 slots, nn_cache.rs:49); one table
-        // serves every game here, so it gets the threads' worth, rounded up to a power of two
-        const uint64_t want = (uint64_t)((double)p.cache_size * (p.num_threads ? p.num_threads : 1) * 1.9) + 1;
-        uint64_t e = 1u << 16;
-        while (e < want && e < (1ULL << 26)) e <<= 1;
-        eng.cache_entries = e;
-    }
-    if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
-    eng.per_slot_maze = gen_maze;
-    eng.maze_stride = (uint32_t)hw * 4u;
-    {
-        // generated mazes: one pool entry per slot (filled when a game starts there); open: the one shared maze
-        const std::vector<uint8_t> pool_init = gen_maze ? std::vector<uint8_t>((size_t)S * hw * 4, (uint8_t)0) : cost;
-        if (int rc = eng.setup(device, S, cfg, p.max_turns, pool_init, arena_nodes, net != nullptr, pool_bytes)) return rc;
-    }
-    tm[0] = since(tp);
-    // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
-    eng.gather_rounds = default_gather_rounds(cfg);
-    if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
-    {
-        // groups of games pipelined against each other (Engine::group_step); AR_GROUPS overrides
-        uint32_t ng = 1;  // measured: more groups do not pay
-        if (const char* e = getenv("AR_GROUPS"))
-            if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
-        if (getenv("AR_NO_ADVANCE_OVERLAP")) eng.overlap_advance = false;
-        if (int rc = eng.make_groups(ng)) return rc;
-    }
-    if (const char* e = getenv("AR_LANES_PER_WAVE"))
-        if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
-
-    BundleSink writer;
-    const bool to_disk = p.output_dir != nullptr;
-    if (to_disk) {
-        writer.dir = p.output_dir;
-        writer.max_games = p.max_games_per_bundle ? p.max_games_per_bundle : 32;
-        writer.start();
-    }
-
-    ArSelfPlayStats st;
-    memset(&st, 0, sizeof st);
-    st.min_turns = 0xFFFFFFFFu;
-    std::vector<HostGame> slot_game(S);
-    uint32_t next_game = 0, finished = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    std::string err;
-
-    auto refill = [&](const std::vector<uint32_t>& free_slots) -> int {
+    int refill(const std::vector<uint32_t>& free_slots) {
         std::vector<GameInit<NW>> inits;
         std::vector<uint8_t> mazes;
         for (uint32_t sl : free_slots) {
-            if (next_game >= p.num_games) break;
-            const uint32_t index = p.first_game_index + next_game;
+            if (!supply_left()) break;
+            const uint32_t index = p.first_game_index + (uint32_t)next_game;  // wraps in an unbounded session
             HostGame g;
-            if (!make_game(index, g, err)) return fail(AR_E_INVALID, err);
+            if (!make_game(index, g)) return fail(AR_E_INVALID, err);
             GameInit<NW> gi;
             memset(&gi, 0, sizeof gi);
             fill_state<NW>(g, gi.board, gi.st, gen_maze ? sl * eng.maze_stride : 0u);
@@ -1846,120 +1835,316 @@ int selfplay_impl(const ArSelfPlayParams& p, int device, ArNet* net, ArProgress*
             ++next_game;
         }
         return eng.start_games(inits, gen_maze ? &mazes : nullptr);
-    };
+    }
 
-    {
-        tp = now();
+    int open(const ArSelfPlayParams& params, int device, ArNet* owned_net, ArProgress* prog, ArGameSink sk, void* sk_user) {
+        p = params;
+        net = owned_net;
+        progress = prog;
+        sink = sk;
+        sink_user = sk_user;
+        memset(&st, 0, sizeof st);
+        st.min_turns = 0xFFFFFFFFu;
+        cfg = to_cfg(p.search, p.simulations, p.batch_size);
+        if (int rc = check_cfg(cfg)) return rc;
+        cost = open_maze_cost(p.width, p.height);
+        hw = p.width * p.height;
+        unbounded = p.num_games == 0xFFFFFFFFu;
+
+        gseed = p.game_seed_base;
+        rseed = p.rng_seed_base;
+        if (!p.has_seed) {  // reference behaviour: entropy (selfplay.rs:622, bindings.rs:530-532)
+            std::random_device rd;
+            gseed = ((uint64_t)rd() << 32) | rd();
+            rseed = ((uint64_t)rd() << 32) | rd();
+        }
+        random_pos = p.positions && std::string(p.positions) == "random";
+        // "classic" = the engine's default walls and mud (bindings.rs:507 with_classic_maze; taken here as density
+        // 0.7 / 0.1, symmetric -- the defaults of the binding's own signature), "random" = the caller's parameters
+        const std::string maze_type = p.maze_type ? p.maze_type : "open";
+        gen_maze = maze_type != "open";
+        wall_d = maze_type == "classic" ? 0.7f : p.wall_density;
+        mud_d = maze_type == "classic" ? 0.1f : p.mud_density;
+        maze_sym = maze_type == "classic" ? true : p.maze_symmetric != 0;
+        to_disk = p.output_dir != nullptr;
+        if (to_disk) {
+            writer.dir = p.output_dir;
+            writer.max_games = p.max_games_per_bundle ? p.max_games_per_bundle : 32;
+        }
+        p.maze_type = p.positions = p.output_dir = p.weights_path = p.device = nullptr;  // caller-owned strings
+
+        // resident games: bounded by the request, the caller's hint and the arena footprint
+        S = p.concurrent_games ? p.concurrent_games : 16384;
+        if (S > p.num_games) S = p.num_games;
+        size_t pool_bytes = 0;
+        const uint32_t arena_nodes = getenv("AR_ARENA_NODES") ? (uint32_t)atoi(getenv("AR_ARENA_NODES")) : 0u;  // test knob
+        t0 = std::chrono::steady_clock::now();
+        if (S == 0) return AR_OK;
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipSetDevice(device) != hipSuccess) return fail(AR_E_DEVICE, "hipSetDevice failed");
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            free_b += arena_cached_bytes(device);  // the block kept from the previous call is ours to reuse
+            const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
+                                    Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr);
+            const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
+            if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
+            if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
+            // the overflow pool gets what is left, minus a reserve for the evaluator's buffers and the
+            // (rare) arenas beyond the largest pool class, which the host allocates one by one
+            const size_t reserve = (size_t)4 << 30;
+            const size_t used = (size_t)S * per_game;
+            pool_bytes = free_b > used + reserve ? (free_b - used - reserve) / 100 * 85 : 0;
+        }
+
+        // AR_TIMING=1 prints where the host wall time of this run went (stderr)
+        timing = getenv("AR_TIMING") != nullptr;
+        auto tp = std::chrono::steady_clock::now();
+        auto since = [](std::chrono::steady_clock::time_point a) {
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+        };
+        eng.net = net;
+        if (p.cache_size && net != nullptr) {
+            // the reference sizes one table per worker thread (capacity x 1.9 slots, nn_cache.rs:49); one table
+            // serves every game here, so it gets the threads' worth, rounded up to a power of two
+            const uint64_t want = (uint64_t)((double)p.cache_size * (p.num_threads ? p.num_threads : 1) * 1.9) + 1;
+            uint64_t e = 1u << 16;
+            while (e < want && e < (1ULL << 26)) e <<= 1;
+            eng.cache_entries = e;
+        }
+        if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
+        eng.per_slot_maze = gen_maze;
+        eng.maze_stride = (uint32_t)hw * 4u;
+        {
+            // generated mazes: one pool entry per slot (filled when a game starts there); open: the one shared maze
+            const std::vector<uint8_t> pool_init = gen_maze ? std::vector<uint8_t>((size_t)S * hw * 4, (uint8_t)0) : cost;
+            if (int rc = eng.setup(device, S, cfg, p.max_turns, pool_init, arena_nodes, net != nullptr, pool_bytes)) return rc;
+        }
+        tm[0] = since(tp);
+        // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
+        eng.gather_rounds = default_gather_rounds(cfg);
+        if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
+        {
+            // groups of games pipelined against each other (Engine::group_step); AR_GROUPS overrides
+            uint32_t ng = 1;  // measured: more groups do not pay
+            if (const char* e = getenv("AR_GROUPS"))
+                if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
+            if (eng.cache_entries) ng = 1;  // one probe/fill pair in flight at a time: a reader never overlaps an eviction
+            if (getenv("AR_NO_ADVANCE_OVERLAP")) eng.overlap_advance = false;
+            if (int rc = eng.make_groups(ng)) return rc;
+        }
+        if (const char* e = getenv("AR_LANES_PER_WAVE"))
+            if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
+        if (to_disk) writer.start();
+        slot_game.resize(S);
+        t0 = std::chrono::steady_clock::now();
+        tp = t0;
         std::vector<uint32_t> all(S);
         for (uint32_t i = 0; i < S; ++i) all[i] = i;
-        if (int rc = refill(all)) {
-            writer.finish();
-            return rc;
-        }
+        if (int rc = refill(all)) return rc;
         tm[1] = since(tp);
+        return AR_OK;
     }
 
-    int rc = AR_OK;
-    // steps between host visits: a game needs ~n_sims/batch steps per move, so a few dozen steps of
-    // latency on refills and arena growth costs little
-    const int iters = 4, launches = 8;
-    while (finished < p.num_games) {
-        tp = now();
-        if ((rc = eng.run_steps(launches, iters)) != AR_OK) break;
-        tm[2] += since(tp);
-        tp = now();
-        uint32_t c[4];
-        if ((rc = eng.scan(c)) != AR_OK) break;
-        tm[3] += since(tp);
-        tp = now();
-        if (c[3] != 0) {
-            rc = fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel (slot.error != 0)");
-            break;
+    // `c` simulate_batch steps for every resident game
+    int run_chunk(uint32_t c) {
+        const uint32_t iters = 4;  // batches one k_step_uniform launch runs per lane before the tree reuse
+        if (c / iters)
+            if (int rc = eng.run_steps((int)(c / iters), (int)iters)) return rc;
+        if (c % iters)
+            if (int rc = eng.run_steps(1, (int)(c % iters))) return rc;
+        return AR_OK;
+    }
+
+    // one finished game: stats, progress, sink, writer (SelfPlayStats::add_game, selfplay.rs:190-210)
+    void account(const DoneInfo<NW>& di, const PosRec<NW>* pos) {
+        const float f1 = di.final_st.s1, f2 = di.final_st.s2;
+        const HostGame& hg = slot_game[di.slot];
+        st.total_games += 1;
+        st.total_positions += di.n_pos;
+        st.total_simulations += di.t_sims;
+        st.total_nn_evals += di.t_nn;
+        st.total_terminals += di.t_term;
+        st.total_collisions += di.t_coll;
+        st.total_cheese_collected += f1 + f2;
+        st.total_cheese_available += hg.total_cheese;
+        if (di.n_pos < st.min_turns) st.min_turns = di.n_pos;
+        if (di.n_pos > st.max_turns) st.max_turns = di.n_pos;
+        if (f1 > f2) st.p1_wins += 1;
+        else if (f2 > f1) st.p2_wins += 1;
+        else st.draws += 1;
+        st.gather_node_visits += di.nv_gather;
+        st.backup_node_visits += di.nv_backup;
+        st.new_nodes += di.new_nodes;
+        // the game leaves the resident set: its part of the last scan's sums moves to the finished totals
+        const unsigned long long part[LIVE_N] = {di.n_pos, di.t_sims, di.t_nn, di.t_term, di.t_coll, di.nv_gather,
+                                                di.nv_backup, di.new_nodes, 1};
+        for (int k = 0; k < LIVE_N; ++k) live[k] = live[k] >= part[k] ? live[k] - part[k] : 0;
+        if (progress) {  // selfplay.rs:637-645
+            __atomic_fetch_add(&progress->positions_completed, (uint64_t)di.n_pos, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&progress->simulations_completed, (uint64_t)di.t_sims, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&progress->nn_evals_completed, (uint64_t)di.t_nn, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&progress->games_completed, 1u, __ATOMIC_RELAXED);
         }
-        if (c[1] && (rc = eng.handle_stalls(c[1], c[2] > 0)) != AR_OK) break;
-        tm[4] += since(tp);
-        tp = now();
-        if (c[0]) {
-            const uint32_t n_done = c[0];
-            if ((rc = eng.drain(n_done)) != AR_OK) break;
-            tm[5] += since(tp);
-            tp = now();
-            std::vector<uint32_t> free_slots;
-            for (uint32_t d = 0; d < n_done; ++d) {
-                const DoneInfo<NW>& di = eng.h_info.p[d];
-                auto rec = std::make_shared<GameRecordHost>();
-                const HostGame& hg = slot_game[di.slot];
-                record_from_device<NW>(di, eng.h_staging.p + (size_t)d * p.max_turns, hg, hg.cost.empty() ? cost : hg.cost, *rec);
-                // SelfPlayStats::add_game (selfplay.rs:190-210)
-                st.total_games += 1;
-                st.total_positions += rec->n;
-                st.total_simulations += rec->sims;
-                st.total_nn_evals += rec->nn;
-                st.total_terminals += rec->term;
-                st.total_collisions += rec->coll;
-                st.total_cheese_collected += rec->final_p1 + rec->final_p2;
-                st.total_cheese_available += rec->cheese_available;
-                if (rec->n < st.min_turns) st.min_turns = rec->n;
-                if (rec->n > st.max_turns) st.max_turns = rec->n;
-                if (rec->result == 1) st.p1_wins += 1;
-                else if (rec->result == 2) st.p2_wins += 1;
-                else st.draws += 1;
-                st.gather_node_visits += di.nv_gather;
-                st.backup_node_visits += di.nv_backup;
-                st.new_nodes += di.new_nodes;
-                if (progress) {  // selfplay.rs:637-645
-                    __atomic_fetch_add(&progress->positions_completed, (uint64_t)rec->n, __ATOMIC_RELAXED);
-                    __atomic_fetch_add(&progress->simulations_completed, rec->sims, __ATOMIC_RELAXED);
-                    __atomic_fetch_add(&progress->nn_evals_completed, rec->nn, __ATOMIC_RELAXED);
-                    __atomic_fetch_add(&progress->games_completed, 1u, __ATOMIC_RELAXED);
-                }
-                if (sink) {
-                    ArGameRecordView v = rec->view();
-                    sink(sink_user, &v);
-                }
-                if (to_disk && rec->n > 0) writer.push(rec);
-                free_slots.push_back(di.slot);
-                ++finished;
+        if (sink || to_disk) {  // the record itself is only built for someone who wants it
+            auto rec = std::make_shared<GameRecordHost>();
+            record_from_device<NW>(di, pos, hg, hg.cost.empty() ? cost : hg.cost, *rec);
+            if (sink) {
+                ArGameRecordView v = rec->view();
+                sink(sink_user, &v);
             }
-            tm[6] += since(tp);
-            tp = now();
-            if ((rc = refill(free_slots)) != AR_OK) break;
-            tm[7] += since(tp);
-        }
-        if (c[0] == 0 && c[1] == 0 && c[2] == 0 && finished < p.num_games && next_game >= p.num_games) {
-            rc = fail(AR_E_DEVICE, "self-play stalled: no active games left but not all games finished");
-            break;
+            if (to_disk && rec->n > 0) writer.push(rec);
         }
     }
-    if (to_disk) {
-        writer.finish();
-        if (rc == AR_OK && !writer.error.empty()) rc = fail(AR_E_IO, writer.error);
+
+    // cumulative figures: finished games + what the resident games have done so far (per finished move)
+    void totals(ArSelfPlayStats& o) const {
+        o = st;
+        o.total_positions += live[0];
+        o.total_simulations += live[1];
+        o.total_nn_evals += live[2];
+        o.total_terminals += live[3];
+        o.total_collisions += live[4];
+        o.gather_node_visits += live[5];
+        o.backup_node_visits += live[6];
+        o.new_nodes += live[7];
+        o.device_secs = eng.device_ms / 1000.0;
+        o.steps = eng.steps;
+        o.gather_secs = eng.gather_ms / 1000.0;
+        o.gather_launches = eng.gather_launches;
     }
-    st.elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (st.total_games == 0) st.min_turns = 0;
-    st.device_secs = eng.device_ms / 1000.0;
-    st.steps = eng.steps;
-    st.gather_secs = eng.gather_ms / 1000.0;
-    st.gather_launches = eng.gather_launches;
-    if (eng.cache_entries) {
+    int read_cache_counters(ArSelfPlayStats& o) {
+        if (!eng.cache_entries) return AR_OK;
         unsigned long long hm[2] = {0, 0};
-        if (hipMemcpy(hm, eng.cache_counters.p, sizeof hm, hipMemcpyDeviceToHost) == hipSuccess) {
-            st.cache_hits = hm[0];
-            st.cache_misses = hm[1];
-        }
+        HIP_TRY(hipMemcpy(hm, eng.cache_counters.p, sizeof hm, hipMemcpyDeviceToHost));
+        o.cache_hits = hm[0];
+        o.cache_misses = hm[1];
+        return AR_OK;
     }
-    if (timing)
-        fprintf(stderr,
-                "[ar timing] games=%u resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "
-                "scan-wait %.3f grow %.3f (%llu) drain %.3f records %.3f refill %.3f | pool blocks %u/%u/%u, fewest free "
-                "%u/%u/%u\n",
-                p.num_games, S, st.elapsed_secs, st.device_secs, tm[0], tm[1], tm[2], tm[3], tm[4],
-                (unsigned long long)eng.grows, tm[5], tm[6], tm[7], eng.pool.n[0], eng.pool.n[1], eng.pool.n[2],
-                eng.pool.n[0] ? eng.pool_low[0] : 0u, eng.pool.n[1] ? eng.pool_low[1] : 0u,
-                eng.pool.n[2] ? eng.pool_low[2] : 0u);
-    *out = st;
-    return rc;
-}
+
+    int step(uint32_t batch_steps, ArSelfPlayStats* window, int* finished_out) override {
+        if (failed) return fail(AR_E_INVALID, "the session has failed earlier; close it");
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(now() - a).count(); };
+        const auto w0 = now();
+        ArSelfPlayStats before;
+        totals(before);
+        if (int rc = read_cache_counters(before)) return rc;
+        uint32_t win_min = 0xFFFFFFFFu, win_max = 0;
+        const ArSelfPlayStats st_before = st;
+        int rc = AR_OK;
+        // steps between host visits: a game needs ~n_sims/batch steps per move, so a few dozen steps of
+        // latency on refills and arena growth costs little
+        const uint32_t visit_every = 32;
+        uint64_t left = batch_steps;
+        while (S > 0 && !all_finished() && left > 0) {
+            const uint32_t chunk = left < visit_every ? (uint32_t)left : visit_every;
+            if (batch_steps != 0xFFFFFFFFu) left -= chunk;
+            auto tp = now();
+            if ((rc = run_chunk(chunk)) != AR_OK) break;
+            tm[2] += since(tp);
+            tp = now();
+            uint32_t c[4];
+            if ((rc = eng.scan(c)) != AR_OK) break;
+            for (int k = 0; k < LIVE_N; ++k) live[k] = eng.h_live.p[k];
+            tm[3] += since(tp);
+            tp = now();
+            if (c[3] != 0) {
+                rc = fail(AR_E_DEVICE, "internal capacity guard tripped in a tree kernel (slot.error != 0)");
+                break;
+            }
+            if (c[1] && (rc = eng.handle_stalls(c[1], c[2] > 0)) != AR_OK) break;
+            tm[4] += since(tp);
+            tp = now();
+            if (c[0]) {
+                const uint32_t n_done = c[0];
+                if ((rc = eng.drain(n_done)) != AR_OK) break;
+                tm[5] += since(tp);
+                tp = now();
+                std::vector<uint32_t> free_slots;
+                for (uint32_t d = 0; d < n_done; ++d) {
+                    const DoneInfo<NW>& di = eng.h_info.p[d];
+                    account(di, eng.h_staging.p + (size_t)d * p.max_turns);
+                    if (di.n_pos < win_min) win_min = di.n_pos;
+                    if (di.n_pos > win_max) win_max = di.n_pos;
+                    free_slots.push_back(di.slot);
+                    ++finished;
+                }
+                tm[6] += since(tp);
+                tp = now();
+                if ((rc = refill(free_slots)) != AR_OK) break;
+                tm[7] += since(tp);
+            }
+            if (c[0] == 0 && c[1] == 0 && c[2] == 0 && !all_finished() && !supply_left()) {
+                rc = fail(AR_E_DEVICE, "self-play stalled: no active games left but not all games finished");
+                break;
+            }
+        }
+        if (rc != AR_OK) failed = true;
+        if (window) {
+            ArSelfPlayStats a;
+            totals(a);
+            if (rc == AR_OK) rc = read_cache_counters(a);
+            ArSelfPlayStats& w = *window;
+            memset(&w, 0, sizeof w);
+            w.total_games = a.total_games - before.total_games;
+            w.total_positions = a.total_positions - before.total_positions;
+            w.total_simulations = a.total_simulations - before.total_simulations;
+            w.total_nn_evals = a.total_nn_evals - before.total_nn_evals;
+            w.total_terminals = a.total_terminals - before.total_terminals;
+            w.total_collisions = a.total_collisions - before.total_collisions;
+            w.gather_node_visits = a.gather_node_visits - before.gather_node_visits;
+            w.backup_node_visits = a.backup_node_visits - before.backup_node_visits;
+            w.new_nodes = a.new_nodes - before.new_nodes;
+            w.p1_wins = st.p1_wins - st_before.p1_wins;
+            w.p2_wins = st.p2_wins - st_before.p2_wins;
+            w.draws = st.draws - st_before.draws;
+            w.total_cheese_collected = st.total_cheese_collected - st_before.total_cheese_collected;
+            w.total_cheese_available = st.total_cheese_available - st_before.total_cheese_available;
+            w.min_turns = w.total_games ? win_min : 0;
+            w.max_turns = win_max;
+            w.cache_hits = a.cache_hits - before.cache_hits;
+            w.cache_misses = a.cache_misses - before.cache_misses;
+            w.device_secs = a.device_secs - before.device_secs;
+            w.steps = a.steps - before.steps;
+            w.gather_secs = a.gather_secs - before.gather_secs;
+            w.gather_launches = a.gather_launches - before.gather_launches;
+            w.elapsed_secs = since(w0);
+        }
+        if (finished_out) *finished_out = (S == 0 || all_finished()) ? 1 : 0;
+        return rc;
+    }
+
+    // Ends the run: bundles flushed, totals of the FINISHED games returned (an unbounded session that is
+    // closed with games in flight simply drops them, like a sampler that is interrupted).
+    int close(ArSelfPlayStats* total) override {
+        int rc = AR_OK;
+        if (to_disk) {
+            writer.finish();
+            to_disk = false;
+            if (!writer.error.empty()) rc = fail(AR_E_IO, writer.error);
+        }
+        ArSelfPlayStats o = st;
+        o.elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (o.total_games == 0) o.min_turns = 0;
+        o.device_secs = eng.device_ms / 1000.0;
+        o.steps = eng.steps;
+        o.gather_secs = eng.gather_ms / 1000.0;
+        o.gather_launches = eng.gather_launches;
+        if (S > 0 && rc == AR_OK) rc = read_cache_counters(o);
+        if (timing)
+            fprintf(stderr,
+                    "[ar timing] games=%llu resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "
+                    "scan-wait %.3f grow %.3f (%llu) drain %.3f records %.3f refill %.3f | pool blocks %u/%u/%u, fewest "
+                    "free %u/%u/%u\n",
+                    (unsigned long long)finished, S, o.elapsed_secs, o.device_secs, tm[0], tm[1], tm[2], tm[3], tm[4],
+                    (unsigned long long)eng.grows, tm[5], tm[6], tm[7], eng.pool.n[0], eng.pool.n[1], eng.pool.n[2],
+                    eng.pool.n[0] ? eng.pool_low[0] : 0u, eng.pool.n[1] ? eng.pool_low[1] : 0u,
+                    eng.pool.n[2] ? eng.pool_low[2] : 0u);
+        if (total) *total = o;
+        return rc;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // single searches
@@ -2029,6 +2214,10 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
     }
     Engine<NW> eng;
     eng.net = predict_fn ? nullptr : net;
+    if (eng.net != nullptr)
+        for (uint32_t i = 0; i < n; ++i)
+            if (games[i].width != net->dev.width || games[i].height != net->dev.height)
+                return fail(AR_E_INVALID, "game size does not match the network's board size");
     if (int rc = eng.setup(device, n, cfg, max_turns, mazes, 0, eng.net != nullptr)) return rc;
     std::vector<GameInit<NW>> inits(n);
     std::random_device rd;
@@ -2127,6 +2316,16 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
 }
 
 }  // namespace
+
+// the evaluator must outlive the engine's streams: the session is destroyed first, then the net
+struct ArSelfPlaySession {
+    SessionBase* impl = nullptr;
+    ArNet* net = nullptr;
+    ~ArSelfPlaySession() {
+        delete impl;
+        if (net) ar_net_free(net);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
@@ -2242,9 +2441,10 @@ int ar_search(const ArGameSpec* game, const ArSearchConfig* cfg, uint32_t simula
                  : search_impl<4>(game, 1, c, seed, predict_fn, user, net, dev, out);
 }
 
-int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink sink, void* sink_user,
-                    ArSelfPlayStats* out) {
+int ar_selfplay_open(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink sink, void* sink_user,
+                     ArSelfPlaySession** out) {
     if (!p || !out) return fail(AR_E_INVALID, "null argument");
+    *out = nullptr;
     const std::string mt = p->maze_type ? p->maze_type : "open";
     if (mt != "open") {
         if (mt != "classic" && mt != "random") return fail(AR_E_INVALID, "unknown maze_type: " + mt);
@@ -2255,14 +2455,55 @@ int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink 
         return fail(AR_E_INVALID, "board must have 1..256 cells");
     int dev = 0;
     if (int rc = parse_device(p->device, p->device_index, dev)) return rc;
-    ArNet* net = nullptr;
+    std::unique_ptr<ArSelfPlaySession> s(new ArSelfPlaySession());
     if (p->weights_path) {
-        if (int rc = ar_net_load(p->weights_path, dev, &net)) return rc;
+        if (int rc = ar_net_load(p->weights_path, dev, &s->net)) return rc;
+        // the reference fails on the ONNX input shape when the model was trained for another board
+        if (s->net->dev.width != p->width || s->net->dev.height != p->height)
+            return fail(AR_E_INVALID, "the network was built for a " + std::to_string(s->net->dev.width) + "x" +
+                                          std::to_string(s->net->dev.height) + " board, the games are " +
+                                          std::to_string(p->width) + "x" + std::to_string(p->height));
     }
-    const int rc = (int)p->width * p->height <= 64 ? selfplay_impl<1>(*p, dev, net, progress, sink, sink_user, out)
-                                                   : selfplay_impl<4>(*p, dev, net, progress, sink, sink_user, out);
-    if (net) ar_net_free(net);
+    int rc;
+    if ((int)p->width * p->height <= 64) {
+        auto* impl = new SelfPlaySession<1>();
+        s->impl = impl;
+        rc = impl->open(*p, dev, s->net, progress, sink, sink_user);
+    } else {
+        auto* impl = new SelfPlaySession<4>();
+        s->impl = impl;
+        rc = impl->open(*p, dev, s->net, progress, sink, sink_user);
+    }
+    if (rc != AR_OK) return rc;
+    *out = s.release();
+    return AR_OK;
+}
+
+int ar_selfplay_step(ArSelfPlaySession* s, uint32_t batch_steps, ArSelfPlayStats* window, int* finished) {
+    if (!s || !s->impl) return fail(AR_E_INVALID, "null session");
+    return s->impl->step(batch_steps, window, finished);
+}
+
+int ar_selfplay_close(ArSelfPlaySession* s, ArSelfPlayStats* total) {
+    if (!s) return AR_OK;
+    const int rc = s->impl ? s->impl->close(total) : AR_OK;
+    delete s;
     return rc;
+}
+
+int ar_selfplay_run(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink sink, void* sink_user,
+                    ArSelfPlayStats* out) {
+    if (!p || !out) return fail(AR_E_INVALID, "null argument");
+    if (p->num_games == 0xFFFFFFFFu) return fail(AR_E_INVALID, "num_games = UINT32_MAX (unbounded) needs a session");
+    memset(out, 0, sizeof *out);
+    ArSelfPlaySession* s = nullptr;
+    if (int rc = ar_selfplay_open(p, progress, sink, sink_user, &s)) return rc;
+    int finished = 0;
+    const int rc = ar_selfplay_step(s, 0xFFFFFFFFu, nullptr, &finished);
+    const std::string msg = g_error;
+    const int rc2 = ar_selfplay_close(s, out);
+    if (rc != AR_OK) return fail(rc, msg);
+    return rc2;
 }
 
 int ar_net_load(const char* blob_path, int device, ArNet** out) {

@@ -976,8 +976,9 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
 }
 
 // per-maze first-layer constants for a pool of `n_mazes` cost tables of this net's board size
+// (always recomputed: a pool at the same address with the same count may hold other mazes -- an engine that
+// died and a new one whose allocation landed on the same block; the kernel is tiny)
 static int net_bind_mazes(ArNet* net, const uint8_t* d_maze_pool, int n_mazes, hipStream_t stream) {
-    if (net->bound_pool == d_maze_pool && net->bound_mazes == n_mazes) return AR_OK;
     if (net->dev.arch == arnet::ARCH_CNN) {  // the CNN reads the maze planes itself
         net->bound_pool = d_maze_pool;
         net->bound_mazes = n_mazes;

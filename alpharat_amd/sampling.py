@@ -135,6 +135,49 @@ def record_to_dict(v: _lib.ArGameRecordView) -> dict:
     return d
 
 
+def _resolve_weights(weights_path, onnx_model_path):
+    """``onnx_model_path`` is accepted for drop-in compatibility: a path ending in ``.onnx`` is mapped to the
+    weight blob next to it (``.arnet``; written from the ``.pt`` checkpoint next to it when missing). The ONNX
+    graph itself is never read or executed."""
+    if weights_path is None and onnx_model_path is not None:
+        p = Path(onnx_model_path)
+        cand = p if p.suffix == ".arnet" else p.with_suffix(".arnet")
+        if not cand.exists() and p.with_suffix(".pt").exists():
+            from .weights import checkpoint_to_blob
+
+            cand = checkpoint_to_blob(p.with_suffix(".pt"))
+        if not cand.exists():
+            raise RuntimeError(f"no weight blob for {onnx_model_path}: expected {cand} "
+                               "(alpharat_amd.weights.checkpoint_to_blob writes it from the .pt checkpoint)")
+        weights_path = str(cand)
+    return weights_path
+
+
+def _params(*, width, height, cheese_count, max_turns, num_games, cheese_symmetric, maze_type, positions, wall_density,
+            mud_density, maze_symmetric, simulations, batch_size, c_puct, fpu_reduction, force_k, noise_epsilon,
+            noise_concentration, collision_limit_min, collision_limit_max, collision_scaling_start,
+            collision_scaling_end, collision_scaling_power, num_threads, output_dir, max_games_per_bundle,
+            weights_path, device, mux_max_batch_size, cache_size, seed, rng_seed_base, first_game_index,
+            concurrent_games, device_index):
+    if device_index is None:
+        device_index = int(os.environ.get("LOCAL_RANK", "0")) if device in ("auto", "hip") else 0
+    if output_dir is not None:
+        Path(output_dir).mkdir(parents=True, exist_ok=True)
+    cfg = _lib.ArSearchConfig(c_puct, fpu_reduction, force_k, noise_epsilon, noise_concentration, collision_limit_min,
+                              collision_limit_max, collision_scaling_start, collision_scaling_end,
+                              collision_scaling_power)
+    enc = lambda s: None if s is None else str(s).encode()  # noqa: E731
+    has_seed = seed is not None
+    return _lib.ArSelfPlayParams(
+        width, height, cheese_count, max_turns, num_games, int(cheese_symmetric), enc(maze_type), enc(positions),
+        wall_density, mud_density, int(maze_symmetric), simulations, batch_size, cfg, num_threads, enc(output_dir),
+        max_games_per_bundle, enc(weights_path), enc(device), mux_max_batch_size, cache_size, int(has_seed),
+        (seed or 0) & 0xFFFFFFFFFFFFFFFF,
+        ((rng_seed_base if rng_seed_base is not None else (0xA1FA0000 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF),
+        first_game_index, concurrent_games, device_index,
+    )
+
+
 def rust_self_play(*, width: int, height: int, cheese_count: int, max_turns: int, num_games: int,
                    cheese_symmetric: bool = True, maze_type: str = "open", positions: str = "corners",
                    wall_density: float = 0.7, mud_density: float = 0.1, maze_symmetric: bool = True,
@@ -155,34 +198,18 @@ def rust_self_play(*, width: int, height: int, cheese_count: int, max_turns: int
     the weight blob next to it (``.arnet``, written by ``alpharat_amd.weights.checkpoint_to_blob``);
     the ONNX graph itself is never executed."""
     L = _lib.load()
-    if weights_path is None and onnx_model_path is not None:
-        p = Path(onnx_model_path)
-        cand = p if p.suffix == ".arnet" else p.with_suffix(".arnet")
-        if not cand.exists() and p.with_suffix(".pt").exists():
-            from .weights import checkpoint_to_blob
-
-            cand = checkpoint_to_blob(p.with_suffix(".pt"))
-        if not cand.exists():
-            raise RuntimeError(f"no weight blob for {onnx_model_path}: expected {cand} "
-                               "(alpharat_amd.weights.checkpoint_to_blob writes it from the .pt checkpoint)")
-        weights_path = str(cand)
-    if device_index is None:
-        device_index = int(os.environ.get("LOCAL_RANK", "0")) if device in ("auto", "hip") else 0
-    if output_dir is not None:
-        Path(output_dir).mkdir(parents=True, exist_ok=True)
-    cfg = _lib.ArSearchConfig(c_puct, fpu_reduction, force_k, noise_epsilon, noise_concentration, collision_limit_min,
-                              collision_limit_max, collision_scaling_start, collision_scaling_end,
-                              collision_scaling_power)
-    enc = lambda s: None if s is None else str(s).encode()  # noqa: E731
-    has_seed = seed is not None
-    p = _lib.ArSelfPlayParams(
-        width, height, cheese_count, max_turns, num_games, int(cheese_symmetric), enc(maze_type), enc(positions),
-        wall_density, mud_density, int(maze_symmetric), simulations, batch_size, cfg, num_threads, enc(output_dir),
-        max_games_per_bundle, enc(weights_path), enc(device), mux_max_batch_size, cache_size, int(has_seed),
-        (seed or 0) & 0xFFFFFFFFFFFFFFFF,
-        ((rng_seed_base if rng_seed_base is not None else (0xA1FA0000 + (seed or 0))) & 0xFFFFFFFFFFFFFFFF),
-        first_game_index, concurrent_games, device_index,
-    )
+    weights_path = _resolve_weights(weights_path, onnx_model_path)
+    p = _params(width=width, height=height, cheese_count=cheese_count, max_turns=max_turns, num_games=num_games,
+                cheese_symmetric=cheese_symmetric, maze_type=maze_type, positions=positions, wall_density=wall_density,
+                mud_density=mud_density, maze_symmetric=maze_symmetric, simulations=simulations, batch_size=batch_size,
+                c_puct=c_puct, fpu_reduction=fpu_reduction, force_k=force_k, noise_epsilon=noise_epsilon,
+                noise_concentration=noise_concentration, collision_limit_min=collision_limit_min,
+                collision_limit_max=collision_limit_max, collision_scaling_start=collision_scaling_start,
+                collision_scaling_end=collision_scaling_end, collision_scaling_power=collision_scaling_power,
+                num_threads=num_threads, output_dir=output_dir, max_games_per_bundle=max_games_per_bundle,
+                weights_path=weights_path, device=device, mux_max_batch_size=mux_max_batch_size, cache_size=cache_size,
+                seed=seed, rng_seed_base=rng_seed_base, first_game_index=first_game_index,
+                concurrent_games=concurrent_games, device_index=device_index)
     out = _lib.ArSelfPlayStats()
     sink = _lib.ArGameSink()
     if on_game is not None:
@@ -190,6 +217,74 @@ def rust_self_play(*, width: int, height: int, cheese_count: int, max_turns: int
     prog = C.byref(progress._c) if progress is not None else None
     _lib.check(L.ar_selfplay_run(C.byref(p), prog, sink, None, C.byref(out)))
     return SelfPlayStats(out)
+
+
+UNBOUNDED = 0xFFFFFFFF
+
+
+class SelfPlaySession:
+    """The same run in slices (include/alpharat_hip.h: ar_selfplay_open / _step / _close): the device engine, its
+    resident games and the supply of new games stay alive between ``step`` calls. ``num_games=UNBOUNDED`` never
+    runs out of games. Takes rust_self_play's keyword arguments.
+
+        with SelfPlaySession(width=7, ..., num_games=UNBOUNDED, concurrent_games=65536) as s:
+            window = s.step(1024)     # SelfPlayStats of what happened inside these 1024 batch steps
+    """
+
+    def __init__(self, *, on_game: Callable[[dict], None] | None = None, progress: SelfPlayProgress | None = None,
+                 onnx_model_path: str | None = None, **kw: Any) -> None:
+        L = _lib.load()
+        defaults = dict(cheese_symmetric=True, maze_type="open", positions="corners", wall_density=0.7, mud_density=0.1,
+                        maze_symmetric=True, batch_size=8, c_puct=1.5, fpu_reduction=0.2, force_k=2.0, noise_epsilon=0.0,
+                        noise_concentration=10.83, collision_limit_min=1, collision_limit_max=256,
+                        collision_scaling_start=800, collision_scaling_end=50_000, collision_scaling_power=1.0,
+                        num_threads=4, output_dir=None, max_games_per_bundle=32, weights_path=None, device="auto",
+                        mux_max_batch_size=256, cache_size=0, seed=None, rng_seed_base=None, first_game_index=0,
+                        concurrent_games=0, device_index=None)
+        defaults.update(kw)
+        defaults["weights_path"] = _resolve_weights(defaults["weights_path"], onnx_model_path)
+        p = _params(**defaults)
+        self._sink = _lib.ArGameSink()
+        if on_game is not None:
+            self._sink = _lib.ArGameSink(lambda _u, v: on_game(record_to_dict(v.contents)))
+        self._progress = progress
+        prog = C.byref(progress._c) if progress is not None else None
+        self._h = C.c_void_p()
+        self.finished = False
+        _lib.check(L.ar_selfplay_open(C.byref(p), prog, self._sink, None, C.byref(self._h)))
+
+    def step(self, batch_steps: int) -> SelfPlayStats:
+        """`batch_steps` simulate_batch steps for every resident game; returns the window's stats."""
+        if not self._h:
+            raise RuntimeError("session is closed")
+        out = _lib.ArSelfPlayStats()
+        fin = C.c_int(0)
+        _lib.check(_lib.load().ar_selfplay_step(self._h, int(batch_steps), C.byref(out), C.byref(fin)))
+        self.finished = bool(fin.value)
+        return SelfPlayStats(out)
+
+    def run_to_end(self) -> SelfPlayStats:
+        return self.step(UNBOUNDED)
+
+    def close(self) -> SelfPlayStats | None:
+        if not self._h:
+            return None
+        out = _lib.ArSelfPlayStats()
+        h, self._h = self._h, C.c_void_p()
+        _lib.check(_lib.load().ar_selfplay_close(h, C.byref(out)))
+        return SelfPlayStats(out)
+
+    def __enter__(self) -> "SelfPlaySession":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        self.close()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def release_device_memory(device_index: int = 0) -> None:

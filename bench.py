@@ -7,23 +7,35 @@
 Workload (config.workload): BASELINE config 3 -- 7x7 open PyRat, 10 symmetric cheese, 50 turns,
 `7x7_rust_tuned` search (1897 sims, c_puct .512, fpu .459, force_k .103, noise eps .25, batch 16),
 PyRatMLP hidden 256 with seeded random weights (throughput does not depend on weight values),
-synthetic seeded games. A "step" is one full pass of the hot path over one batch of `--games`
-games per GPU: every game is played to the end (search -> sample -> move -> reuse tree, every turn).
-Games are sharded over ranks with no collective in the data path (weak scaling: per-GPU games fixed).
+synthetic seeded games.
 
-value = MCTS simulations per second over all ranks (the reference's own count: the sum of root
-visit totals, selfplay.rs:547); games/s, nn_evals/s and productive descents/s ride along as
-extra keys. The timed region starts with everything resident on the device.
+The sampler runs as ONE persistent session per GPU (ar_selfplay_open / _step / _close): `--resident`
+games live on the device, every finished game is replaced at once from an endless seeded supply, exactly
+like the reference's workers claim the next game from a queue (selfplay.rs:609-650, bench_selfplay.rs:213-270).
+A "step" is one bounded slice of that run: `--batch-steps` passes of the hot path (gather -> evaluate ->
+backup, + tree reuse for the games that moved) over all resident games. Warm-up steps bring the session to
+its steady state (games at every stage of their life); the timed steps then measure it. Games are sharded
+over ranks with no collective in the data path (weak scaling: per-GPU resident games fixed).
+
+value = MCTS simulations per second over all ranks (the reference's own count: the sum of root visit
+totals of the moves finished inside the timed region, selfplay.rs:547 -- visits kept by tree reuse count);
+productive descents/s (evaluations + terminals, what the search actually walks) and NN evaluations/s ride
+along, as do games/s. The timed region starts with everything resident on the device.
+
+Extra, non-headline evaluators: --evaluator symmetric (BASELINE config 4: SymmetricMLP h256, 7x7_rust_strong,
+2693 sims), --evaluator cnn (config 5: CNN + global pooling c64, 4096 sims), --evaluator uniform (tree kernels only).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 from pathlib import Path
 
+T_START = time.perf_counter()
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
@@ -31,18 +43,50 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes of the tree kernels
 B_NODE_VISIT, B_NEW_NODE, B_NN_LEAF = 300, 304, 1444
-# HBM traffic of one k_gather launch at the default workload, from the PMC passes committed in
-# profiles/r01_v6_pmc_hbm_traffic_default.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs):
-# FETCH_SIZE 551 052 KB per dispatch, doubled as MI355X_MICROARCH.md prescribes for gfx950 (the factor is
-# calibrated for wide streaming reads; these are scattered 16-byte reads, so it is an upper bound),
-# WRITE_SIZE 540 052 KB per dispatch as read.
-PMC_GATHER_FETCH_KB, PMC_GATHER_WRITE_KB = 551052.0, 540052.0
 B_SELECT_VISIT = 204  # the select half of SURVEY 8d's 300 B node-visit (192 B read + 12 B virtual-loss writes)
 B_LEAF_REQ = 40  # one evaluator request written by the gather: position + slot id
 
-SEARCH = dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83)
 GAME = dict(width=7, height=7, cheese_count=10, max_turns=50)
-SIMS, BATCH = 1897, 16
+WORKLOADS = {
+    # evaluator: (search kwargs, sims, batch, description)
+    "mlp": (dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83), 1897, 16,
+            "7x7_rust_tuned (1897 sims, batch 16, noise 0.25), PyRatMLP h256 random weights"),
+    "uniform": (dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83), 1897, 16,
+                "7x7_rust_tuned (1897 sims, batch 16, noise 0.25), SmartUniform priors"),
+    "symmetric": (dict(c_puct=0.512, fpu_reduction=0.479, force_k=0.025, noise_epsilon=0.25, noise_concentration=10.83), 2693, 16,
+                  "7x7_rust_strong (2693 sims, batch 16, noise 0.25), SymmetricMLP h256 random weights"),
+    "cnn": (dict(c_puct=0.512, fpu_reduction=0.459, force_k=0.103, noise_epsilon=0.25, noise_concentration=10.83), 4096, 16,
+            "4096 sims (tuned constants, batch 16, noise 0.25), PyRatCNN c64 res,res,gpool(32) random weights"),
+}
+# sources whose change invalidates a committed PMC traffic measurement of the tree kernels
+TRAFFIC_SOURCES = ("dev_search.h", "dev_engine.h", "dev_rng.h", "slot_layout.h", "alpharat_hip.hip")
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for name in TRAFFIC_SOURCES:
+        h.update((ROOT / "alpharat_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel: str, evaluator: str, resident: int):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (tools/pmc_traffic.py
+    writes profiles/traffic.json). Counters cannot be read from inside this process, so the figure is only
+    reported when it was measured on exactly these kernel sources and this workload; otherwise null."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None, None
+    try:
+        t = json.loads(f.read_text())
+    except ValueError:
+        return None, None
+    if t.get("source_hash") != kernel_source_hash() or t.get("evaluator") != evaluator or t.get("resident") != resident:
+        return None, f"profiles/traffic.json is stale (measured on sources {t.get('source_hash')}, {t.get('evaluator')}, " \
+                     f"{t.get('resident')} resident)"
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    return k["bytes_per_launch"], t.get("source")
 
 
 def make_mlp_blob(path: Path) -> Path:
@@ -53,6 +97,7 @@ def make_mlp_blob(path: Path) -> Path:
 
     if path.exists():
         return path
+    path.parent.mkdir(parents=True, exist_ok=True)
     rng = np.random.default_rng(0)
     d, h = 7 * 7 * 7 + 6, 256
     t = {}
@@ -70,23 +115,41 @@ def make_mlp_blob(path: Path) -> Path:
     return write_blob(path, "mlp", 7, 7, t)
 
 
-def cpu_baseline(blob: Path, evaluator: str) -> dict:
-    """The oracle's self-play loop (one game per OS thread, the reference's worker structure) timed on
-    this box's host cores over a bounded sample of the same workload."""
+def weights_for(evaluator: str, rank: int) -> str | None:
+    if evaluator == "uniform":
+        return None
+    if evaluator == "mlp":
+        blob = ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet"
+        if rank == 0:
+            make_mlp_blob(blob)
+        return str(blob)
+    # the seeded random networks of the parity tests (tools/gen_net_golden.py)
+    name = {"symmetric": "symmetric_7x7_h256", "cnn": "cnn_gpool_7x7_c64"}[evaluator]
+    return str(ROOT / "tests" / "golden" / "nets" / f"{name}.arnet")
+
+
+def cpu_baseline(blob: str | None, evaluator: str, max_secs: float) -> dict:
+    """The oracle's self-play loop (the reference's worker structure: OS threads claiming games from an atomic
+    counter, 16 games per thread like bench_selfplay.rs:213) timed on this box's host cores over a BOUNDED
+    sample of the same workload: no thread claims a new game after `max_secs`. value = sum over threads of
+    (simulations of the thread / time its last game ended), so the ragged end of the sample does not count."""
     import _oracle as O
 
+    search, sims, batch, _ = WORKLOADS[evaluator]
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
-    cfg = O.make_config(**SEARCH)
-    net = O.Net(blob) if evaluator == "mlp" else None
-    games = threads  # one game per thread: ~10-30 s of CPU work
-    r = O.selfplay_bench(GAME["width"], GAME["height"], GAME["cheese_count"], GAME["max_turns"], games, cfg, SIMS, BATCH,
-                         threads, backend=2 if net else 0, net=net)
+    cfg = O.make_config(**search)
+    net = O.Net(blob) if blob else None
+    games = 16 * threads
+    r = O.selfplay_bench(GAME["width"], GAME["height"], GAME["cheese_count"], GAME["max_turns"], games, cfg, sims, batch,
+                         threads, backend=2 if net else 0, net=net, max_secs=max_secs)
     return {
-        "value": r["simulations"] / r["elapsed_secs"], "unit": "simulations/s", "cores": threads, "kind": "port",
-        "sample": f"{games} games of the same workload, {threads} threads, one game per thread "
-                  f"({r['positions']} positions, {r['elapsed_secs']:.1f} s)",
-        "games_per_sec": games / r["elapsed_secs"],
+        "value": r["thread_rate_sum"], "unit": "simulations/s", "cores": threads, "kind": "port",
+        "sample": f"{r['games']} games of the same workload finished by {threads} threads claiming from a queue of "
+                  f"{games} until {max_secs:.0f} s had passed ({r['positions']} positions, {r['elapsed_secs']:.1f} s wall); "
+                  "sum of per-thread rates",
+        "wall_rate": r["simulations"] / r["elapsed_secs"],
+        "games_per_sec": r["games"] / r["elapsed_secs"],
         "descents_per_sec": (r["nn_evals"] + r["terminals"]) / r["elapsed_secs"],
     }
 
@@ -94,13 +157,16 @@ def cpu_baseline(blob: Path, evaluator: str) -> dict:
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=262144, help="games per GPU per step")
-    ap.add_argument("--resident", type=int, default=65536,
-                    help="games resident on the GPU at once (one lane each; finished games are replaced from the rest)")
-    ap.add_argument("--evaluator", choices=["mlp", "uniform"], default="mlp")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-steps", type=int, default=1024,
+                    help="passes of the hot path (gather -> evaluate -> backup) over all resident games per step")
+    ap.add_argument("--resident", type=int, default=65536, help="games resident on each GPU (one lane each)")
+    ap.add_argument("--evaluator", choices=sorted(WORKLOADS), default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-secs", type=float, default=15.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--deadline", type=float, default=480.0,
+                    help="seconds after process start at which the timed loop stops early and reports the steps done")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,25 +199,13 @@ def main() -> int:
         dist_mod.init_process_group(backend)
         dist = dist_mod
         dist.barrier()
-    from alpharat_amd.sampling import rust_self_play
+    from alpharat_amd import _lib
+    from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession
 
-    blob = make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet") if rank == 0 else None
+    search, sims, batch, workload = WORKLOADS[args.evaluator]
+    weights = weights_for(args.evaluator, rank)
     if dist is not None:
         dist.barrier()
-    blob = ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet"
-    weights = str(blob) if args.evaluator == "mlp" else None
-
-    def one_step(step_idx: int):
-        # game ids are global and disjoint across ranks and steps; per-GPU work is fixed (weak scaling)
-        first = (step_idx * world + rank) * args.games
-        return rust_self_play(**GAME, num_games=args.games, simulations=SIMS, batch_size=BATCH, output_dir=None,
-                              weights_path=weights, seed=0, first_game_index=first, concurrent_games=min(args.resident, args.games),
-                              device_index=local_rank, **SEARCH)
-
-    for w in range(args.warmup):
-        one_step(-1 - w)
-
-    from alpharat_amd import _lib
 
     def sync():
         # device-wide sync through the library (hipDeviceSynchronize) + torch's too when it is loaded
@@ -163,26 +217,37 @@ def main() -> int:
                 torch.cuda.synchronize()
             dist.barrier()
 
+    # game ids are global and disjoint across ranks: rank r plays r * 2^28, r * 2^28 + 1, ... (weak scaling)
+    session = SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
+                              weights_path=weights, seed=0, first_game_index=rank << 28, concurrent_games=args.resident,
+                              device_index=local_rank, **search)
+    t_open = time.perf_counter() - T_START
+    for _ in range(args.warmup):
+        session.step(args.batch_steps)
+
     sync()
     t0 = time.perf_counter()
-    stats = None
-    dev_secs = gather_secs = 0.0
-    dev_steps = gather_launches = 0
+    acc = None
+    done = 0
     for k in range(args.steps):
-        s = one_step(k)
-        stats = s if stats is None else stats + s
-        # sequential passes: device times and launch counts add up (SelfPlayStats.__add__ merges parallel shards)
-        dev_secs += s.device_secs
-        dev_steps += s.steps
-        gather_secs += s.gather_secs
-        gather_launches += s.gather_launches
+        w = session.step(args.batch_steps)
+        acc = w if acc is None else _sum_windows(acc, w)
+        done += 1
+        # insurance against a kill: a provisional line after every timed step (stderr + a file; stdout carries
+        # exactly one line, the final one)
+        _progress(rank, {"provisional": True, "steps_done": done, "value": acc.total_simulations * world / (time.perf_counter() - t0),
+                         "unit": "simulations/s (this rank x world)"})
+        if time.perf_counter() - T_START > args.deadline and done < args.steps:
+            print(f"bench: deadline of {args.deadline:.0f} s reached after {done} of {args.steps} timed steps", file=sys.stderr)
+            break
     sync()
     elapsed = time.perf_counter() - t0
+    session.close()
+    stats = acc
 
     tot = dict(sims=stats.total_simulations, games=stats.total_games, nn=stats.total_nn_evals,
                desc=stats.total_nn_evals + stats.total_terminals, positions=stats.total_positions,
-               nv=stats.gather_node_visits + stats.backup_node_visits, new=stats.new_nodes)
-    tree_secs = dev_secs
+               nv=stats.gather_node_visits + stats.backup_node_visits, new=stats.new_nodes, done=done)
     if dist is not None:
         import torch
 
@@ -193,71 +258,107 @@ def main() -> int:
         v = torch.tensor([float(x) for x in tot.values()], dtype=torch.float64, device=red_dev)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         tot = dict(zip(tot.keys(), [float(x) for x in v.tolist()]))
+        tot["done"] = tot["done"] / world
     if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
         return 0
 
     # roofline of the dominant kernel, k_gather (rank 0's own counters): algorithmic bytes of one launch =
     # SURVEY.md 8d's per-unit figures x the units one launch processes (node records inspected on the way
     # down, nodes created, leaf positions handed to the evaluator), divided by the launch's duration from
     # HIP events recorded on the kernel's own stream around every launch.
+    has_net = args.evaluator != "uniform"
     gather_bytes = (B_SELECT_VISIT * stats.gather_node_visits + B_NEW_NODE * stats.new_nodes
-                    + (B_LEAF_REQ * stats.total_nn_evals if args.evaluator == "mlp" else 0))
-    launches = max(gather_launches, 1)
-    if args.evaluator == "mlp" and gather_secs > 0:
-        avg_launch_s = gather_secs / launches
-        achieved = gather_bytes / launches / avg_launch_s / 1e9
+                    + (B_LEAF_REQ * stats.total_nn_evals if has_net else 0))
+    if has_net and stats.gather_secs > 0:
+        launches = max(stats.gather_launches, 1)
+        avg_launch_s = stats.gather_secs / launches
         kernel = "k_gather"
     else:  # SmartUniform: one fused step kernel, timed as a whole
         gather_bytes += (B_NODE_VISIT - B_SELECT_VISIT) * stats.backup_node_visits
-        launches = max(dev_steps, 1)
-        avg_launch_s = tree_secs / launches
-        achieved = gather_bytes / launches / max(avg_launch_s, 1e-12) / 1e9
+        launches = max(stats.steps, 1)
+        avg_launch_s = stats.device_secs / launches
         kernel = "k_step_uniform (+ k_advance)"
+    achieved = gather_bytes / launches / max(avg_launch_s, 1e-12) / 1e9
     step_bytes = (B_NODE_VISIT * (stats.gather_node_visits + stats.backup_node_visits) + B_NEW_NODE * stats.new_nodes
-                  + (B_NN_LEAF * stats.total_nn_evals if args.evaluator == "mlp" else 0))
+                  + (B_NN_LEAF * stats.total_nn_evals if has_net else 0))
+    traffic, traffic_source = committed_traffic("k_gather" if has_net else "k_step_uniform", args.evaluator, args.resident)
     out = {
         "metric": "MCTS simulations/sec, self-play 7x7 PyRat at the tuned 1897-sim config",
         "value": tot["sims"] / elapsed,
         "unit": "simulations/s",
         "n_gpus": world,
-        "steps": args.steps,
+        "steps": int(tot["done"]),
         "warmup": args.warmup,
-        "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+        "ms_per_step": elapsed / max(tot["done"], 1) * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "7x7 open PyRat, 10 cheese, 50 turns, 7x7_rust_tuned (1897 sims, batch 16, noise 0.25), "
-                               + ("PyRatMLP h256 random weights" if args.evaluator == "mlp" else "SmartUniform priors"),
-                   "games_per_gpu_per_step": args.games, "resident_games_per_gpu": min(args.resident, args.games),
+        "config": {"workload": "7x7 open PyRat, 10 cheese, 50 turns, " + workload,
+                   "step": f"{args.batch_steps} passes of gather -> evaluate -> backup (+ tree reuse) over all resident games "
+                           "of a persistent session; finished games are replaced at once from an endless seeded supply",
+                   "resident_games_per_gpu": args.resident, "batch_steps_per_step": args.batch_steps,
                    "parallelism": f"games sharded over {world} GPU(s), no collective"},
-        "games_per_sec": tot["games"] / elapsed,
-        "nn_evals_per_sec": tot["nn"] / elapsed,
+        # the three rates side by side: `value` counts root visits per finished move, which includes the visits
+        # a reused subtree brings along; descents are what the search actually walks; evaluations are network calls
+        "simulations_per_sec": tot["sims"] / elapsed,
         "descents_per_sec": tot["desc"] / elapsed,
+        "nn_evals_per_sec": tot["nn"] / elapsed,
+        "games_per_sec": tot["games"] / elapsed,
+        "positions_per_sec": tot["positions"] / elapsed,
         "avg_turns": tot["positions"] / max(tot["games"], 1),
         "node_visits_per_sec": tot["nv"] / elapsed,
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            # PMC counters cannot be read inside this process: the figure is the committed measurement of this
-            # exact workload (same games / resident / evaluator), null for any other
-            "traffic": ((2.0 * PMC_GATHER_FETCH_KB + PMC_GATHER_WRITE_KB) * 1024.0
-                        if (kernel == "k_gather" and args.games == 262144 and min(args.resident, args.games) == 65536)
-                        else None),
-            "traffic_source": "profiles/r01_v6_pmc_hbm_traffic_default.txt (bytes per k_gather launch; FETCH_SIZE x2 + WRITE_SIZE)",
+            # HBM bytes per launch from the PMC passes committed under profiles/ -- null unless they were taken on
+            # exactly these kernel sources and this workload (counters cannot be read inside this process)
+            "traffic": traffic, "traffic_source": traffic_source, "kernel_source_hash": kernel_source_hash(),
             "kernel": kernel, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
             "algorithmic_bytes_per_launch": gather_bytes / launches,
             # the whole step (gather + evaluator + backup, tree reuse overlapped) for reference
-            "step": {"batch_steps": dev_steps, "device_secs": tree_secs, "avg_step_ms": tree_secs / max(dev_steps, 1) * 1e3,
-                     "algorithmic_bytes": step_bytes, "achieved_GBps": step_bytes / max(tree_secs, 1e-9) / 1e9},
+            "step": {"batch_steps": stats.steps, "device_secs": stats.device_secs,
+                     "avg_step_ms": stats.device_secs / max(stats.steps, 1) * 1e3, "algorithmic_bytes": step_bytes,
+                     "achieved_GBps": step_bytes / max(stats.device_secs, 1e-9) / 1e9},
         },
+        "timing": {"session_open_s": t_open, "timed_s": elapsed},
     }
     if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline(blob, args.evaluator)
-    print(json.dumps(out))
+        left = args.deadline + 60.0 - (time.perf_counter() - T_START)
+        if left > args.cpu_secs + 15.0:
+            out["cpu_baseline"] = cpu_baseline(weights, args.evaluator, args.cpu_secs)
+        else:
+            out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0
+
+
+def _sum_windows(a, b):
+    """Consecutive windows of one session: counters and times add up."""
+    from alpharat_amd.sampling import SelfPlayStats
+
+    kw = {k: getattr(a, k) + getattr(b, k) for k in SelfPlayStats._RAW}
+    kw["min_turns"] = min(x for x in (a.min_turns, b.min_turns) if x) if (a.min_turns or b.min_turns) else 0
+    kw["max_turns"] = max(a.max_turns, b.max_turns)
+    return SelfPlayStats(**kw)
+
+
+def _progress(rank: int, line: dict) -> None:
+    if rank != 0:
+        return
+    s = json.dumps(line)
+    print(s, file=sys.stderr, flush=True)
+    try:
+        d = ROOT / "gpurun_out"
+        d.mkdir(exist_ok=True)
+        with open(d / "bench_progress.jsonl", "a") as f:
+            f.write(s + "\n")
+    except OSError:
+        pass
 
 
 if __name__ == "__main__":

@@ -219,6 +219,24 @@ typedef void (*ArGameSink)(void* user, const ArGameRecordView* game);
 int ar_selfplay_run(const ArSelfPlayParams* params, ArProgress* progress, ArGameSink sink, void* sink_user,
                     ArSelfPlayStats* out);
 
+/* ---- the same run in slices (extension; the reference's worker pool lives for one call, selfplay.rs:721-808).
+ * A session keeps the device engine, its resident games and the supply of new games alive between calls:
+ *   ar_selfplay_open   sets up `concurrent_games` resident games (num_games == UINT32_MAX: the supply never
+ *                      ends; game indices continue from first_game_index and wrap);
+ *   ar_selfplay_step   runs `batch_steps` simulate_batch steps (search.rs:961) for every resident game
+ *                      (UINT32_MAX: until all games are finished), with finished games drained to the sink /
+ *                      bundle writer and their slots refilled, and reports in `window` what was done inside
+ *                      this call: games finished, and positions / simulations / evaluations / node-visits per
+ *                      finished MOVE (games still in flight count with the moves they completed);
+ *                      *finished = 1 when no game is left;
+ *   ar_selfplay_close  flushes the bundles, returns the totals of the finished games and frees everything.
+ * ar_selfplay_run(p, ...) == open; step(UINT32_MAX); close. */
+typedef struct ArSelfPlaySession ArSelfPlaySession;
+int ar_selfplay_open(const ArSelfPlayParams* params, ArProgress* progress, ArGameSink sink, void* sink_user,
+                     ArSelfPlaySession** out);
+int ar_selfplay_step(ArSelfPlaySession* session, uint32_t batch_steps, ArSelfPlayStats* window, int* finished);
+int ar_selfplay_close(ArSelfPlaySession* session, ArSelfPlayStats* total);
+
 /* Bundle writer on its own (recording.rs:23-162 write_bundle): used by the known-answer test. */
 int ar_write_bundle(const ArGameRecordView* games, uint32_t n, const char* path);
 

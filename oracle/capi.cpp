@@ -135,10 +135,63 @@ int or_net_forward(const void* n, const float* obs, int count, int obs_dim, floa
     return 0;
 }
 
-// backend_kind: 0 SmartUniform, 1 constant values (value args), 2 net blob, 3 always failing
+// A host evaluator supplied by the test: the reference's Backend trait object (backend.rs:75-82) as a C
+// callback. The parity tests plug the product's HIP evaluator in here (through its C-ABI), so the oracle's
+// search sees bit for bit the network outputs the device pipeline sees and whole-game records can be
+// compared byte for byte. leaves[i] = {p1x, p1y, p2x, p2y, p1_mud, p2_mud, turn, pad, p1_score, p2_score
+// (float bits), cheese mask bits 0..255 as 8 x u32}; out[i] = policy_p1[5] policy_p2[5] v1 v2.
+struct OrLeaf {
+    uint8_t p1x, p1y, p2x, p2y, p1_mud, p2_mud;
+    uint16_t turn;
+    float p1_score, p2_score;
+    uint32_t cheese[8];
+};
+typedef int (*OrEvalFn)(void* user, const OrLeaf* leaves, uint32_t n, float* out12);
+struct OrCallback {
+    OrEvalFn fn;
+    void* user;
+};
+
+// backend_kind: 0 SmartUniform, 1 constant values (value args), 2 net blob, 3 always failing,
+// 4 host callback (`net` points to an OrCallback)
 static Backend make_backend(int kind, float v1, float v2, const void* net) {
     if (kind == 0) return smart_uniform_backend();
     if (kind == 1) return smart_uniform_backend(v1, v2);
+    if (kind == 4) {
+        const OrCallback cb = *(const OrCallback*)net;
+        return [cb](const std::vector<const GameState*>& games, std::vector<EvalResult>& out, std::string& e) {
+            std::vector<OrLeaf> leaves(games.size());
+            std::vector<float> res(games.size() * 12);
+            for (size_t i = 0; i < games.size(); ++i) {
+                const GameState& g = *games[i];
+                OrLeaf& l = leaves[i];
+                std::memset(&l, 0, sizeof l);
+                l.p1x = g.player1.x;
+                l.p1y = g.player1.y;
+                l.p2x = g.player2.x;
+                l.p2y = g.player2.y;
+                l.p1_mud = g.player1.mud_timer;
+                l.p2_mud = g.player2.mud_timer;
+                l.turn = g.turn;
+                l.p1_score = g.player1.score;
+                l.p2_score = g.player2.score;
+                for (int c = 0; c < g.cells(); ++c)
+                    if (g.has_cheese(c)) l.cheese[c >> 5] |= 1u << (c & 31);
+            }
+            if (cb.fn(cb.user, leaves.data(), (uint32_t)leaves.size(), res.data()) != 0) {
+                e = "host evaluator callback failed";
+                return false;
+            }
+            out.resize(games.size());
+            for (size_t i = 0; i < games.size(); ++i) {
+                std::memcpy(out[i].policy_p1, &res[i * 12], 20);
+                std::memcpy(out[i].policy_p2, &res[i * 12 + 5], 20);
+                out[i].value_p1 = res[i * 12 + 10];
+                out[i].value_p2 = res[i * 12 + 11];
+            }
+            return true;
+        };
+    }
     if (kind == 3)
         return [](const std::vector<const GameState*>&, std::vector<EvalResult>&, std::string& e) {
             e = "test failure";
@@ -423,22 +476,30 @@ void or_record_positions(const void* rp, int32_t* ints, float* floats, uint8_t* 
 // ---- CPU baseline: the reference's worker-thread structure (selfplay.rs:609-703): one game per
 // OS thread claimed by atomic index. Game i: cheese seed game_seed_base+i, search rng seed
 // rng_seed_base+i (the reference seeds from entropy; fixed seeds here so runs are repeatable).
+// `max_secs` > 0 bounds the sample: after that long no thread claims another game (the games in progress
+// are finished). Every thread notes when its own last game ended, so the caller can add up per-thread rates
+// (work of thread t / busy time of thread t) instead of dividing by the time of the slowest thread.
 // out: [games, positions, simulations, nn_evals, terminals, collisions, gather_nv, backup_nv, new_nodes]
+// thread_secs (optional, [threads]) and thread_sims (optional, [threads]): busy time and simulations per thread
 int or_selfplay_bench(uint8_t w, uint8_t h, uint16_t cheese, uint16_t max_turns, uint32_t n_games,
                       const OrSearchConfig* cfg, uint32_t n_sims, uint32_t batch, uint32_t threads,
                       uint64_t game_seed_base, uint64_t rng_seed_base, int backend_kind, const void* net,
-                      uint64_t out[9], double* elapsed_secs) {
+                      uint64_t out[9], double* elapsed_secs, double max_secs, double* thread_secs,
+                      uint64_t* thread_sims) {
     std::atomic<uint32_t> next{0};
     std::atomic<int> failed{0};
     std::vector<std::vector<uint64_t>> acc(threads, std::vector<uint64_t>(9, 0));
+    std::vector<double> busy(threads, 0.0);
     SearchConfig sc = to_cfg(cfg);
     auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<std::thread> pool;
     for (uint32_t t = 0; t < threads; ++t)
         pool.emplace_back([&, t]() {
             Backend be = make_backend(backend_kind, 0, 0, net);
             std::string err;
             for (;;) {
+                if (max_secs > 0.0 && secs() >= max_secs) break;
                 uint32_t i = next.fetch_add(1);
                 if (i >= n_games) break;
                 GameState g;
@@ -463,13 +524,18 @@ int or_selfplay_bench(uint8_t w, uint8_t h, uint16_t cheese, uint16_t max_turns,
                 a[6] += rec.counters.gather_node_visits;
                 a[7] += rec.counters.backup_node_visits;
                 a[8] += rec.counters.new_nodes;
+                busy[t] = secs();
             }
         });
     for (auto& th : pool) th.join();
-    *elapsed_secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *elapsed_secs = secs();
     for (int k = 0; k < 9; ++k) {
         out[k] = 0;
         for (uint32_t t = 0; t < threads; ++t) out[k] += acc[t][k];
+    }
+    for (uint32_t t = 0; t < threads; ++t) {
+        if (thread_secs) thread_secs[t] = busy[t];
+        if (thread_sims) thread_sims[t] = acc[t][2];
     }
     return failed ? -1 : 0;
 }

@@ -127,7 +127,8 @@ def lib() -> C.CDLL:
         "or_record_positions": (None, [vp, vp, vp, vp]),
         "or_selfplay_bench": (
             i32,
-            [u8, u8, u16, u16, u32, C.POINTER(OrSearchConfig), u32, u32, u32, u64, u64, i32, vp, vp, C.POINTER(C.c_double)],
+            [u8, u8, u16, u16, u32, C.POINTER(OrSearchConfig), u32, u32, u32, u64, u64, i32, vp, vp, C.POINTER(C.c_double),
+             C.c_double, vp, vp],
         ),
     }
     for name, (res, args) in sig.items():
@@ -359,15 +360,72 @@ def play_game(game: Game, cfg: OrSearchConfig, n_sims, batch, rng_seed, backend=
 
 
 def selfplay_bench(w, h, cheese, max_turns, n_games, cfg, n_sims, batch, threads, game_seed_base=0,
-                   rng_seed_base=0xA1FA0000, backend=0, net: Net | None = None) -> dict:
+                   rng_seed_base=0xA1FA0000, backend=0, net: Net | None = None, max_secs=0.0) -> dict:
+    """`max_secs` > 0: no thread claims a new game after that long. `thread_rate_sum` adds up the per-thread
+    rates (simulations of a thread / the time its last game ended)."""
     out = np.zeros(9, dtype=np.uint64)
     el = C.c_double(0)
+    tsecs = np.zeros(threads, dtype=np.float64)
+    tsims = np.zeros(threads, dtype=np.uint64)
     rc = lib().or_selfplay_bench(w, h, cheese, max_turns, n_games, C.byref(cfg), n_sims, batch, threads,
-                                 game_seed_base, rng_seed_base, backend, net.n if net else None, _ptr(out), C.byref(el))
+                                 game_seed_base, rng_seed_base, backend, net.n if net else None, _ptr(out), C.byref(el),
+                                 float(max_secs), _ptr(tsecs), _ptr(tsims))
     if rc != 0:
         raise RuntimeError("oracle selfplay bench failed")
     keys = ["games", "positions", "simulations", "nn_evals", "terminals", "collisions", "gather_node_visits",
             "backup_node_visits", "new_nodes"]
     d = {k: int(v) for k, v in zip(keys, out)}
     d["elapsed_secs"] = el.value
+    ok = tsecs > 0
+    d["thread_rate_sum"] = float((tsims[ok] / tsecs[ok]).sum()) if ok.any() else 0.0
     return d
+
+
+class OrLeaf(C.Structure):
+    _fields_ = [("p1x", C.c_uint8), ("p1y", C.c_uint8), ("p2x", C.c_uint8), ("p2y", C.c_uint8), ("p1_mud", C.c_uint8),
+                ("p2_mud", C.c_uint8), ("turn", C.c_uint16), ("p1_score", C.c_float), ("p2_score", C.c_float),
+                ("cheese", C.c_uint32 * 8)]
+
+
+OrEvalFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(OrLeaf), C.c_uint32, C.POINTER(C.c_float))
+
+
+class OrCallback(C.Structure):
+    _fields_ = [("fn", OrEvalFn), ("user", C.c_void_p)]
+
+
+class CallbackBackend:
+    """Backend kind 4: `evaluate(leaves: list[dict]) -> (p1[n,5], p2[n,5], v1[n], v2[n])` called by the oracle's
+    search for every leaf batch. A leaf dict has p1, p2 (x, y), p1_mud, p2_mud, turn, p1_score, p2_score and
+    `cheese` (uint8[256] mask, idx = y*w + x). Pass as `net=` with `backend=4`."""
+
+    def __init__(self, evaluate):
+        self.calls = 0
+        self.sizes = []
+
+        def _fn(_user, leaves, n, out):
+            try:
+                ls = []
+                for i in range(n):
+                    l = leaves[i]
+                    bits = np.frombuffer(bytes(l.cheese), dtype=np.uint8)
+                    ls.append(dict(p1=(l.p1x, l.p1y), p2=(l.p2x, l.p2y), p1_mud=l.p1_mud, p2_mud=l.p2_mud, turn=l.turn,
+                                   p1_score=l.p1_score, p2_score=l.p2_score,
+                                   cheese=np.unpackbits(bits, bitorder="little")))
+                p1, p2, v1, v2 = evaluate(ls)
+                res = np.concatenate([np.asarray(p1, np.float32).reshape(n, 5), np.asarray(p2, np.float32).reshape(n, 5),
+                                      np.asarray(v1, np.float32).reshape(n, 1), np.asarray(v2, np.float32).reshape(n, 1)],
+                                     axis=1)
+                C.memmove(out, res.ctypes.data, n * 48)
+                self.calls += 1
+                self.sizes.append(n)
+                return 0
+            except Exception:  # noqa: BLE001 -- reported to the oracle as an evaluator failure
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._fn = OrEvalFn(_fn)
+        self._cb = OrCallback(self._fn, None)
+        self.n = C.addressof(self._cb)
