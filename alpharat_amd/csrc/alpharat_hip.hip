@@ -2545,39 +2545,66 @@ int specs_to_device(const ArGameSpec* games, uint32_t n, std::vector<LeafReq<NW>
     return AR_OK;
 }
 
+// grow-only device buffer kept inside the ArNet between ar_net_evaluate calls (callers such as a predict_fn
+// adaptor evaluate a handful of positions thousands of times: five allocations per call cost more than the network)
+static int scratch_reserve(ArNet* net, int which, size_t bytes, void** out) {
+    ArNet::Scratch& sc = net->scratch[which];
+    if (sc.bytes < bytes) {
+        if (sc.p) hipFree(sc.p);
+        sc.p = nullptr;
+        sc.bytes = 0;
+        const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+        if (hipMalloc(&sc.p, want) != hipSuccess) return fail(AR_E_NOMEM, "device allocation failed (evaluator scratch)");
+        sc.bytes = want;
+    }
+    *out = sc.p;
+    return AR_OK;
+}
+
 template <int NW>
 int net_evaluate_impl(ArNet* net, const ArGameSpec* games, uint32_t n, float* pp1, float* pp2, float* pv1, float* pv2,
                       float* lg1, float* lg2) {
     std::vector<LeafReq<NW>> reqs;
     std::vector<Board> boards;
     std::vector<uint8_t> mazes;
-    if (int rc = specs_to_device<NW>(games, n, reqs, boards, mazes)) return rc;
     for (uint32_t i = 0; i < n; ++i)
         if (games[i].width != net->dev.width || games[i].height != net->dev.height)
             return fail(AR_E_INVALID, "game size does not match the network's board size");
+    if (int rc = specs_to_device<NW>(games, n, reqs, boards, mazes)) return rc;
+    // positions on the same maze share one pool entry (the usual case: a batch of leaves of one game)
+    const size_t per = (size_t)net->dev.hw * 4;
+    bool one_maze = true;
+    for (uint32_t i = 1; i < n && one_maze; ++i) one_maze = memcmp(&mazes[i * per], &mazes[0], per) == 0;
+    if (one_maze) {
+        mazes.resize(per);
+        for (uint32_t i = 0; i < n; ++i) boards[i].maze_off = 0;
+    }
+    const int n_mazes = one_maze ? 1 : (int)n;
     HIP_TRY(hipSetDevice(net->device));
-    DevBuf<LeafReq<NW>> d_req;
-    DevBuf<Board> d_boards;
-    DevBuf<uint8_t> d_maze;
-    DevBuf<EvalOut> d_out;
-    DevBuf<float> d_logits;
-    HIP_TRY(d_req.alloc(n));
-    HIP_TRY(d_boards.alloc(n));
-    HIP_TRY(d_maze.alloc(mazes.size()));
-    HIP_TRY(d_out.alloc(n));
-    HIP_TRY(d_logits.alloc((size_t)n * 10));
-    HIP_TRY(hipMemcpy(d_req.p, reqs.data(), sizeof(LeafReq<NW>) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_boards.p, boards.data(), sizeof(Board) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_maze.p, mazes.data(), mazes.size(), hipMemcpyHostToDevice));
-    if (int rc = net_bind_mazes(net, d_maze.p, (int)n, nullptr)) return rc;
-    int rc = net_launch<NW>(net, d_req.p, nullptr, n, (const char*)d_boards.p, sizeof(Board), d_out.p, d_logits.p, nullptr);
+    LeafReq<NW>* d_req = nullptr;
+    Board* d_boards = nullptr;
+    uint8_t* d_maze = nullptr;
+    EvalOut* d_out = nullptr;
+    float* d_logits = nullptr;
+    if (int rc = scratch_reserve(net, 0, sizeof(LeafReq<NW>) * n, (void**)&d_req)) return rc;
+    if (int rc = scratch_reserve(net, 1, sizeof(Board) * n, (void**)&d_boards)) return rc;
+    if (int rc = scratch_reserve(net, 2, mazes.size(), (void**)&d_maze)) return rc;
+    if (int rc = scratch_reserve(net, 3, sizeof(EvalOut) * n, (void**)&d_out)) return rc;
+    if (int rc = scratch_reserve(net, 4, (size_t)n * 40, (void**)&d_logits)) return rc;
+    HIP_TRY(hipMemcpy(d_req, reqs.data(), sizeof(LeafReq<NW>) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_boards, boards.data(), sizeof(Board) * n, hipMemcpyHostToDevice));
+    // the maze constants are only recomputed when the mazes' bytes (not just their address) differ from the last call's
+    if (net->scratch_mazes != mazes || net->bound_pool != d_maze || net->bound_mazes != n_mazes) {
+        HIP_TRY(hipMemcpy(d_maze, mazes.data(), mazes.size(), hipMemcpyHostToDevice));
+        if (int rc = net_bind_mazes(net, d_maze, n_mazes, nullptr)) return rc;
+        net->scratch_mazes = mazes;
+    }
+    int rc = net_launch<NW>(net, d_req, nullptr, n, (const char*)d_boards, sizeof(Board), d_out, d_logits, nullptr);
     if (rc != AR_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    net->bound_pool = nullptr;  // the pool above dies with this call
     std::vector<EvalOut> out(n);
     std::vector<float> logits((size_t)n * 10);
-    HIP_TRY(hipMemcpy(out.data(), d_out.p, sizeof(EvalOut) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(logits.data(), d_logits.p, logits.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out.data(), d_out, sizeof(EvalOut) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(logits.data(), d_logits, logits.size() * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < n; ++i) {
         memcpy(pp1 + (size_t)i * 5, out[i].p1, 20);
         memcpy(pp2 + (size_t)i * 5, out[i].p2, 20);

@@ -806,10 +806,18 @@ struct ArNet {
     const uint8_t* bound_pool = nullptr;
     int bound_mazes = 0;
     size_t smem = 0;
+    // ar_net_evaluate's own buffers (requests, boards, mazes, outputs, logits) and the maze bytes they hold
+    struct Scratch {
+        void* p = nullptr;
+        size_t bytes = 0;
+    } scratch[5];
+    std::vector<uint8_t> scratch_mazes;
 
     ~ArNet() {
         for (void* p : allocs) hipFree(p);
         if (cmaze) hipFree(cmaze);
+        for (Scratch& sc : scratch)
+            if (sc.p) hipFree(sc.p);
     }
     const float* upload(const std::vector<float>& v, bool& ok) {
         float* d = nullptr;
