@@ -28,6 +28,7 @@
 #include "nets.h"
 #include "npz_writer.h"
 #include "slot_layout.h"
+#include "dev_gather8.h"
 #include "zig_norm_tables.inc"
 
 using namespace ar;
@@ -258,6 +259,113 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
     }
     s.status = tag_status(s.status, phase);
     slots[i] = s;
+}
+
+// The same gather with eight lanes per game (dev_gather8.h): a wavefront holds eight games, an octet of lanes walks
+// one tree together. Launched with ceil(n / 8) blocks of 64 threads. Trees, batch entries, counters and the leaf
+// queue contents per game are identical to k_gather's; only the order in which games append to the queue differs.
+template <int NW, int WPE>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_gather8(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
+                                                uint32_t phase, uint32_t accept_ready) {
+    const uint32_t ol = threadIdx.x & 7u;
+    const uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
+    bool run = i < n_slots;
+    if (run) {
+        const uint32_t st = slots[i].status;
+        run = st == SLOT_ACTIVE || st == accept_ready;
+    }
+    const uint32_t ii = i < n_slots ? i : first;  // idle octets read a valid slot and store nothing
+    Slot<NW>& S = slots[ii];
+    const Mem<NW> m = resolve_mem<NW>(S, B.arena, B.scratch, ii, B.L, B.maze);
+    const Board board = S.board;
+    Oct<NW> o;
+    o.done = true;
+    o.alloc_left = 0;
+    o.error = 0;
+    o.d_new = o.d_visits = 0;
+    o.batch_active = S.batch_active;
+    bool stalled = false;
+    // a batch that was already gathered and still waits for its backup is left alone
+    const bool begin = run && o.batch_active == 0;
+    if (begin) {
+        // gather_begin (dev_search.h)
+        o.hi = S.hi;
+        o.cap = S.cap;
+        o.root = S.root;
+        o.node_count = S.node_count;
+        const uint32_t remaining = S.remaining;
+        o.batch = remaining < cfg.batch_size ? remaining : cfg.batch_size;
+        if (o.hi + o.batch > o.cap) {
+            stalled = true;
+        } else {
+            o.left = (long long)(int32_t)collisions_left(o.node_count, cfg);
+            o.n_proc = o.n_coll = o.b_nn = o.b_term = o.b_coll = 0;
+            o.depth = 0;
+            o.node = 0;
+            o.mask = 0;
+            o.omap0 = o.omap1 = 0;
+            o.pick_mv = 0;
+            o.have_pick = false;
+            o.root_st = S.st;
+            o.work = o.root_st;
+            o.rng = S.rng;
+            o.n1 = o.n2 = 0;
+            o.forced = 0;
+            for (int k = 0; k < 2; ++k) {
+                o.sc[k] = o.util[k] = o.num[k] = 0.0f;
+                o.ns[k] = o.add[k] = o.nif0[k] = 0;
+            }
+            for (int k = 0; k < 4; ++k) {
+                o.kid[k] = NIL;
+                o.vtp[k] = 0;
+            }
+            o.done = false;
+        }
+    }
+    for (uint32_t guard = 0; guard < (1u << 22); ++guard) {  // (every game's gather ends; the bound is a fuse)
+        if (!__any(!o.done)) break;
+        gather8_round(o, board, m, cfg, ol);
+    }
+    if (!run) return;
+    if (begin && !stalled && !o.done) o.error = 8;  // the fuse blew
+    uint32_t status = SLOT_ACTIVE;
+    if (stalled) status = SLOT_STALL;
+    if (begin && !stalled) {
+        uint32_t base = 0;
+        const bool complete = o.done && o.batch_active != 0;
+        if (complete && queue != nullptr && o.b_nn > 0) {
+            if (ol == 0) base = atomicAdd(queue_count, o.b_nn);
+            base = oct_pick(base, 0);
+            for (uint32_t j = ol; j < o.b_nn; j += 8) {
+                LeafReq<NW> r;
+                r.st = m.leaf_local[j];
+                r.slot = i;
+                r.pad = 0;
+                queue[base + j] = r;
+            }
+        }
+        if (ol == 0) {
+            S.hi = o.hi;
+            S.node_count = o.node_count;
+            S.new_nodes += o.d_new;
+            S.nv_gather += o.d_visits;
+            S.n_proc = o.n_proc;
+            S.n_coll = o.n_coll;
+            S.b_nn = o.b_nn;
+            S.b_term = o.b_term;
+            S.b_coll = o.b_coll;
+            S.batch_active = o.batch_active;
+            S.eval_base = base;
+            S.rng = o.rng;
+            S.gather_pending = 0;
+            if (o.error) S.error = o.error;
+        }
+    }
+    if (ol == 0) {
+        if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
+        S.status = tag_status(status, phase);
+    }
 }
 
 template <int NW>
@@ -1060,6 +1168,12 @@ struct ArenaHold {
     ~ArenaHold() { arena_release(dev, blk); }
 };
 
+// Which gather kernel the network path uses when AR_GATHER does not say: measured on the bench workload (DESIGN.md
+// section 7, profiles/r02_gather_ab.md) the eight-lanes-per-game kernel is 1.9x / 1.7x / 1.07x faster per launch at
+// 1024 / 8192 / 32768 resident games (its eight-fold wavefront count fills the SIMDs the lane-per-game kernel
+// leaves to one wavefront each) and 1.18x slower at 65536, where it executes 3.4x the instructions.
+static bool default_gather8(uint32_t resident_games) { return resident_games <= 32768u; }
+
 template <int NW>
 struct Engine {
     int dev = 0;
@@ -1111,6 +1225,8 @@ struct Engine {
     DevBuf<unsigned long long> cache_counters;
     ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
+    bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
+    int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
@@ -1181,6 +1297,11 @@ struct Engine {
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventCreateWithFlags(&ev_order, hipEventDisableTiming));
         L = make_layout<NW>(cfg, max_turns);
+        static_assert(sizeof(LevelO<NW>) <= (16 + 112 + sizeof(State<NW>) + 15) / 16 * 16, "slot_layout.h sizes the level stack");
+        // which gather kernel walks the trees of the network path (results are identical): AR_GATHER=lane | octet
+        gather8 = default_gather8(S);
+        if (const char* e = getenv("AR_GATHER")) gather8 = std::string(e) == "octet" || std::string(e) == "octet4";
+        if (const char* e = getenv("AR_GATHER")) gather8_wpe = std::string(e) == "octet4" ? 4 : 2;
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
@@ -1362,8 +1483,15 @@ struct Engine {
             }
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used], g.stream));
         }
-        hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                           qc, gather_rounds, lanes, g.first, phase, ready);
+        if (gather8 && gather8_wpe == 4)
+            hipLaunchKernelGGL((k_gather8<NW, 4>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                               qc, g.first, phase, ready);
+        else if (gather8)
+            hipLaunchKernelGGL((k_gather8<NW, 2>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                               qc, g.first, phase, ready);
+        else
+            hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg,
+                               bases(), q, qc, gather_rounds, lanes, g.first, phase, ready);
         if (timed_launch) {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
@@ -1935,6 +2063,7 @@ struct SelfPlaySession : SessionBase {
         }
         if (const char* e = getenv("AR_LANES_PER_WAVE"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = false;  // the round limit parks lane state: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();

@@ -764,6 +764,176 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric(NetDev net, const ar::Le
     }
 }
 
+// ---- SymmetricMLP on the matrix cores (hidden width a multiple of 32, at most 256) ----------------------
+// One block = 32 leaves, four wavefronts; wavefront w owns output columns 64 w .. 64 w + 63 of every layer
+// (two 32x32 accumulator tiles). Every layer is the k-ordered chain k_symmetric's loops compute -- products
+// with a 0 input add nothing, a one-hot input adds the weight row itself -- so the two kernels give the same
+// bits; here the weights stream through once per block and the multiply-adds run on v_mfma_f32_32x32x2_f32:
+//   shared encoder   acc = maze constant;  k over [cheese mask hw | progress]            (operand from registers)
+//   player encoder   acc = bias;           k over [position one-hot hw | mud | score]    (operand from registers)
+//   trunk 1          acc = bias;           k over the shared encoding, then the player's (LDS A, LDS B)
+//   trunk 2          acc = bias;           k over trunk 1                                (LDS B)
+//   heads            on v_mfma_f32_16x16x4_f32: k over h_p, then over h_1 + h_2          (LDS A, LDS B)
+// Two LDS activation buffers are enough: a layer's output waits in the accumulators until every wavefront has
+// read the buffer it will overwrite, and player 1's trunk output h_1 stays in registers while player 2 is
+// computed (it only has to be in LDS for the heads).
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                             uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                             ar::EvalOut* out, float* logits) {
+    constexpr int L = 32;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4;
+    float* bufA = smem;                    // shared encoding, later h_1          [L][ld]
+    float* bufB = smem + (size_t)L * ld;   // player encoding / trunk 1, later h_2 [L][ld]
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    __shared__ float hl[L * 12];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
+    const int c1 = two ? 32 : 0;
+    // this lane's leaf (row r of the tile) as first-layer operands
+    const LeafFeat f = feat[r];
+    unsigned long long ch[NW];
+    for (int w = 0; w < NW; ++w) ch[w] = cheese[r][w];
+    f32x16 c[1][2], h1[2];
+    auto store_relu = [&](float* buf) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+            buf[(size_t)i * ld + n0 + r] = fmaxf(c[0][0][v], 0.0f);
+            if (two) buf[(size_t)i * ld + n0 + 32 + r] = fmaxf(c[0][1][v], 0.0f);
+        }
+    };
+    auto init_bias = [&](const float* bias) {
+        const float b0 = bias[n0 + r], b1 = bias[n0 + c1 + r];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            c[0][0][v] = b0;
+            c[0][1][v] = b1;
+        }
+    };
+    // ---- shared encoder -> A
+    if (has) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+            const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + n0 + r;
+            c[0][0][v] = cm[0];
+            c[0][1][v] = cm[c1];
+        }
+        auto x_sh = [&](int k, int) -> float {
+            const int kk = k + h;
+            if (kk < hw) {
+                unsigned long long word = ch[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) word = (kk >> 6) == w ? ch[w] : word;
+                return (word >> (kk & 63)) & 1ULL ? 1.0f : 0.0f;
+            }
+            return kk == hw ? f.sc[1] : 0.0f;
+        };
+        mfma_pass<1, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, hw + 1, H, h, x_sh, c);
+        store_relu(bufA);
+    }
+    for (int p = 0; p < 2; ++p) {
+        // ---- player encoder -> B (everybody is done reading B: see the barriers below)
+        if (has) {
+            init_bias(net.bp);
+            const int pos = p == 0 ? f.p1 : f.p2;
+            const float mud = f.sc[2 + p], score = f.sc[4 + p];
+            auto x_pe = [&](int k, int) -> float {
+                const int kk = k + h;
+                if (kk < hw) return kk == pos ? 1.0f : 0.0f;
+                return kk == hw ? mud : kk == hw + 1 ? score : 0.0f;
+            };
+            mfma_pass<1, 8>(net.wpt + (size_t)h * H + n0 + r, two, hw + 2, H, h, x_pe, c);
+            store_relu(bufB);
+        }
+        __syncthreads();
+        // ---- trunk 1: k over A (shared), then over B (player); result waits in the accumulators
+        if (has) {
+            init_bias(net.b2);
+            const float* ap = bufA + (size_t)r * ld + h;
+            auto a_sh = [&](int k, int) -> float { return ap[k]; };
+            mfma_pass<1, 8>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_sh, c);
+            const float* bp = bufB + (size_t)r * ld + h;
+            auto a_pe = [&](int k, int) -> float { return bp[k]; };
+            mfma_pass<1, 8>(net.w2t + (size_t)(H + h) * H + n0 + r, two, H, H, h, a_pe, c);
+        }
+        __syncthreads();
+        if (has) store_relu(bufB);
+        __syncthreads();
+        // ---- trunk 2: k over B
+        if (has) {
+            init_bias(net.b3);
+            const float* bp = bufB + (size_t)r * ld + h;
+            auto a_t1 = [&](int k, int) -> float { return bp[k]; };
+            mfma_pass<1, 8>(net.w3t + (size_t)h * H + n0 + r, two, H, H, h, a_t1, c);
+            if (p == 0) {
+                h1[0] = c[0][0];
+                h1[1] = c[0][1];
+            }
+        }
+        __syncthreads();  // B may be overwritten (next player's encoding, or h_2)
+    }
+    if (has) {
+        store_relu(bufB);  // h_2
+        c[0][0] = h1[0];
+        c[0][1] = h1[1];
+        store_relu(bufA);  // h_1 (the shared encoding is no longer needed)
+    }
+    __syncthreads();
+    // ---- heads on cat(h_p, h_1 + h_2): wavefront = (player, 16-leaf half); rows: policy 5, value 1
+    {
+        const int pl = wave >> 1, half = wave & 1, rr = lane & 15, qq = lane >> 4;
+        const bool col = rr < 6;
+        const float* hp = (pl == 0 ? bufA : bufB) + (size_t)(half * 16 + rr) * ld + qq;
+        const float* ha = bufA + (size_t)(half * 16 + rr) * ld + qq;
+        const float* hb = bufB + (size_t)(half * 16 + rr) * ld + qq;
+        const float* wp = net.wh + (size_t)(col ? rr : 0) * (2 * H) + qq;
+        const float b = col ? net.bh[rr] : 0.0f;
+        f32x4 acc = {b, b, b, b};
+#pragma unroll 8
+        for (int k = 0; k < H; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[k], col ? wp[k] : 0.0f, acc, 0, 0, 0);
+#pragma unroll 8
+        for (int k = 0; k < H; k += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[k] + hb[k], col ? wp[H + k] : 0.0f, acc, 0, 0, 0);
+        if (col)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hl[(half * 16 + 4 * qq + v) * 12 + pl * 6 + rr] = acc[v];
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 6, o.p2);
+        o.v1 = softplusf(hh[5]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 5; ++k) {
+                logits[(size_t)(base + tid) * 10 + k] = hh[k];
+                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
+            }
+    }
+}
+__host__ __device__ inline bool symmetric_mfma_ok(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
+
 // flat observation (flat_encoder.rs:52-125), one block per position
 template <int NW>
 __global__ void k_encode(const ar::LeafReq<NW>* q, uint32_t n, const ar::Board* boards, const uint8_t* maze_pool,
@@ -1022,7 +1192,9 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     if (n_max == 0) return AR_OK;
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
     static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
-    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE : TILE_SYM;
+    const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA");
+    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
+                                                                        : sym_mfma ? 32 : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_CNN) {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_cnn<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1047,6 +1219,13 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
                 hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
         hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
+                           board_stride, out, logits);
+    } else if (sym_mfma) {
+        const size_t smem = (size_t)2 * 32 * (net->dev.H + 4) * 4;
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric_mfma<NW>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
+        hipLaunchKernelGGL(k_symmetric_mfma<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
     } else {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric<NW>,

@@ -24,7 +24,11 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     L.coll_off = off;
     off = align_up(off + sizeof(CollEntry) * L.coll_cap, 64);
     L.levels_off = off;
-    off = align_up(off + sizeof(Level<NW>) * L.max_depth, 64);
+    // (the octet gather's level record, dev_gather8.h LevelO: header 16 B + 28 visit words + position, 16-byte
+    // aligned, is the larger one)
+    const size_t level_o = align_up(16 + 112 + sizeof(State<NW>), 16);
+    const size_t level_bytes = sizeof(Level<NW>) > level_o ? sizeof(Level<NW>) : level_o;
+    off = align_up(off + level_bytes * L.max_depth, 64);
     L.ev_off = off;
     off = align_up(off + sizeof(EvalOut) * cfg.batch_size, 64);
     L.leaf_off = off;

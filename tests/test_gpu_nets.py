@@ -59,6 +59,26 @@ def test_device_net_matches_reference_outputs(name):
         np.testing.assert_allclose(out[k], gold[k], atol=1e-5, rtol=1e-5, err_msg=f"{name}:{k}")
 
 
+@pytest.mark.parametrize("name,w,h", [("symmetric_5x5_h32", 5, 5), ("symmetric_7x7_h256", 7, 7)])
+def test_symmetric_on_matrix_cores_gives_the_bits_of_the_fma_loops(name, w, h, monkeypatch):
+    """k_symmetric_mfma accumulates every output as the same k-ordered chain as k_symmetric's loops (AR_SYM_FMA=1),
+    whatever tile row a leaf lands in: 70 positions (two full 32-leaf tiles and a ragged one), compared bit for bit,
+    and again in another order."""
+    from alpharat_amd.nets import Net
+
+    gold = np.load(GOLD / "nets" / f"{name}.npz")
+    games = [_game_from_obs(o, w, h) for o in gold["obs"]]
+    games = (games * 3)[:70]
+    net = Net(GOLD / "nets" / f"{name}.arnet")
+    a = net.evaluate(games)
+    b = net.evaluate(games[::-1])
+    monkeypatch.setenv("AR_SYM_FMA", "1")
+    c = net.evaluate(games)
+    for k in a:
+        assert a[k].tobytes() == c[k].tobytes(), k
+        assert a[k].tobytes() == b[k][::-1].tobytes(), k
+
+
 def test_search_with_device_net_close_to_oracle_net():
     """Search driven by the device MLP vs the oracle search driven by the oracle MLP. Network outputs
     agree to ~1e-6, not bit for bit, so this checks the plumbing (priors, values, visit totals), not
@@ -110,7 +130,9 @@ def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
 
     base = run(AR_GROUPS=1)
     for env in (dict(AR_GROUPS=3), dict(AR_GROUPS=2, AR_GATHER_ROUNDS=5), dict(AR_ALLOC_PER_ROUND=1, AR_LANES_PER_WAVE=16),
-                dict(AR_GROUPS=4, AR_ALLOC_PER_ROUND=7, AR_GATHER_ROUNDS=11), dict(AR_NO_ADVANCE_OVERLAP=1)):
+                dict(AR_GROUPS=4, AR_ALLOC_PER_ROUND=7, AR_GATHER_ROUNDS=11), dict(AR_NO_ADVANCE_OVERLAP=1),
+                dict(AR_GATHER="lane"), dict(AR_GATHER="octet"), dict(AR_GATHER="octet4", AR_GROUPS=2),
+                dict(AR_GATHER="octet", AR_ALLOC_PER_ROUND=3, AR_NO_ADVANCE_OVERLAP=1)):
         other = run(**env)
         assert sorted(other) == sorted(base)
         for i, g in base.items():
