@@ -232,10 +232,16 @@ template <int NW>
 __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t max_rounds,
                                                uint32_t lanes, uint32_t first, uint32_t phase,
-                                               uint32_t accept_ready) {
-    // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64)
+                                               uint32_t accept_ready, const uint32_t* list, const uint32_t* list_n) {
+    // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64);
+    // with a `list` (k_partition): the games list[0 .. *list_n)
     if (threadIdx.x >= lanes) return;
-    const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
+    uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
+    if (list != nullptr) {
+        const uint32_t j = blockIdx.x * lanes + threadIdx.x;
+        if (j >= *list_n) return;
+        i = list[j];
+    }
     if (i >= n_slots) return;
     {
         const uint32_t st = slots[i].status;
@@ -267,9 +273,17 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
 template <int NW, int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_gather8(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                 LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready) {
+                                                uint32_t phase, uint32_t accept_ready, const uint32_t* list,
+                                                const uint32_t* list_n) {
     const uint32_t ol = threadIdx.x & 7u;
-    const uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
+    uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
+    if (list != nullptr) {  // (k_partition) the games list[0 .. *list_n)
+        uint32_t n_list = *list_n;
+        if (n_list > gridDim.x * 8u) n_list = gridDim.x * 8u;  // (k_partition caps the list at the grid's size)
+        if (blockIdx.x * 8u >= n_list) return;  // whole block beyond the list
+        const uint32_t j = blockIdx.x * 8u + (threadIdx.x >> 3);
+        i = j < n_list ? list[j] : 0xFFFFFFFFu;
+    }
     bool run = i < n_slots;
     if (run) {
         const uint32_t st = slots[i].status;
@@ -277,13 +291,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
     const uint32_t ii = i < n_slots ? i : first;  // idle octets read a valid slot and store nothing
     Slot<NW>& S = slots[ii];
-    const Mem<NW> m = resolve_mem<NW>(S, B.arena, B.scratch, ii, B.L, B.maze);
+    OctMem<NW> m;
+    m.stats = (NodeStats*)(B.arena + S.stats_off);
+    m.kids = (NodeKids*)(B.arena + S.kids_off);
+    m.scratch = B.scratch;
+    m.maze = B.maze;
+    m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
+    m.maze_off = S.board.maze_off;
+    m.proc_off = (uint32_t)B.L.proc_off;
+    m.coll_off = (uint32_t)B.L.coll_off;
+    m.levels_off = (uint32_t)B.L.levels_off;
+    m.leaf_off = (uint32_t)B.L.leaf_off;
+    m.coll_cap = B.L.coll_cap;
+    m.max_depth = B.L.max_depth;
     const Board board = S.board;
+    __shared__ OctShared<NW> shared[8];
+    OctShared<NW>& sh = shared[threadIdx.x >> 3];
     Oct<NW> o;
     o.done = true;
     o.alloc_left = 0;
     o.error = 0;
     o.d_new = o.d_visits = 0;
+    o.rounds = 0;
     o.batch_active = S.batch_active;
     bool stalled = false;
     // a batch that was already gathered and still waits for its backup is left alone
@@ -307,9 +336,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             o.omap0 = o.omap1 = 0;
             o.pick_mv = 0;
             o.have_pick = false;
-            o.root_st = S.st;
-            o.work = o.root_st;
-            o.rng = S.rng;
+            o.work = S.st;
+            sh.rng = S.rng;  // (all eight lanes store the same values: see best_of5)
+            sh.root_st = S.st;
             o.n1 = o.n2 = 0;
             o.forced = 0;
             for (int k = 0; k < 2; ++k) {
@@ -323,10 +352,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             o.done = false;
         }
     }
+    __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
     for (uint32_t guard = 0; guard < (1u << 22); ++guard) {  // (every game's gather ends; the bound is a fuse)
         if (!__any(!o.done)) break;
-        gather8_round(o, board, m, cfg, ol);
+        gather8_round(o, sh, board, m, cfg, ol);
     }
+    __syncthreads();
     if (!run) return;
     if (begin && !stalled && !o.done) o.error = 8;  // the fuse blew
     uint32_t status = SLOT_ACTIVE;
@@ -339,7 +370,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             base = oct_pick(base, 0);
             for (uint32_t j = ol; j < o.b_nn; j += 8) {
                 LeafReq<NW> r;
-                r.st = m.leaf_local[j];
+                r.st = m.leaves()[j];
                 r.slot = i;
                 r.pad = 0;
                 queue[base + j] = r;
@@ -357,14 +388,76 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             S.b_coll = o.b_coll;
             S.batch_active = o.batch_active;
             S.eval_base = base;
-            S.rng = o.rng;
+            S.rng = sh.rng;
             S.gather_pending = 0;
+            S.g_rounds = o.rounds;
             if (o.error) S.error = o.error;
         }
     }
     if (ol == 0) {
         if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
         S.status = tag_status(status, phase);
+    }
+}
+
+// Two gather kernels side by side: games whose last gather took more than `ctrl[0]` rounds (deep trees, many
+// collisions: the few that decide how long a lane-per-game launch lasts) go to the eight-lanes-per-game kernel, which
+// finishes a long walk several times sooner; the rest stay one per lane. k_partition splits the runnable games of
+// this step into the two lists and histograms their round counts; k_threshold turns the histogram into the cut for
+// the NEXT step (the `frac` largest). ctrl: [0] cut, [1] light count, [2] heavy count, [8..8+64) histogram.
+enum { PART_BINS = 64, PART_BIN_W = 8 };
+template <int NW>
+__global__ void k_partition(const Slot<NW>* slots, uint32_t n_slots, uint32_t first, uint32_t accept_ready,
+                            uint32_t* ctrl, uint32_t* light, uint32_t* heavy, uint32_t heavy_cap) {
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    bool runnable = false, is_heavy = false;
+    if (i < n_slots) {
+        const uint32_t st = slots[i].status;
+        runnable = (st == SLOT_ACTIVE || st == accept_ready) && slots[i].batch_active == 0;
+        if (runnable) {
+            const uint32_t r = slots[i].g_rounds;
+            is_heavy = r > ctrl[0];
+            const uint32_t b = r / PART_BIN_W;
+            atomicAdd(&ctrl[8 + (b < PART_BINS ? b : PART_BINS - 1)], 1u);
+        }
+    }
+    const unsigned long long ml = __ballot(runnable && !is_heavy), mh = __ballot(runnable && is_heavy);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t bl = 0, bh = 0;
+    if (lane == 0) {
+        if (ml) bl = atomicAdd(&ctrl[1], (uint32_t)__popcll(ml));
+        if (mh) bh = atomicAdd(&ctrl[2], (uint32_t)__popcll(mh));
+    }
+    bl = (uint32_t)__shfl((int)bl, 0, 64);
+    bh = (uint32_t)__shfl((int)bh, 0, 64);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    if (runnable && !is_heavy) light[bl + (uint32_t)__popcll(ml & below)] = i;
+    if (runnable && is_heavy) {
+        const uint32_t pos = bh + (uint32_t)__popcll(mh & below);
+        if (pos < heavy_cap) heavy[pos] = i;
+        else light[atomicAdd(&ctrl[1], 1u)] = i;  // the heavy kernel's grid is full: one per lane after all
+    }
+}
+__global__ void k_threshold(uint32_t* ctrl, float frac, uint32_t max_heavy) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t total = 0;
+    for (int b = 0; b < PART_BINS; ++b) total += ctrl[8 + b];
+    uint32_t want = (uint32_t)((float)total * frac);
+    if (want > max_heavy) want = max_heavy;
+    uint32_t above = 0;
+    int cut = PART_BINS;  // bins >= cut are heavy
+    for (int b = PART_BINS - 1; b >= 1; --b) {
+        if (above + ctrl[8 + b] > want) break;
+        above += ctrl[8 + b];
+        cut = b;
+    }
+    ctrl[0] = (uint32_t)cut * PART_BIN_W - 1u;  // heavy: rounds > cut * width - 1, i.e. rounds in bin >= cut
+    ctrl[3] = ctrl[1];  // last step's list sizes and histogram, for AR_PART_DEBUG
+    ctrl[4] = ctrl[2];
+    ctrl[1] = ctrl[2] = 0;
+    for (int b = 0; b < PART_BINS; ++b) {
+        ctrl[8 + PART_BINS + b] = ctrl[8 + b];
+        ctrl[8 + b] = 0;
     }
 }
 
@@ -1173,6 +1266,7 @@ struct ArenaHold {
 // 1024 / 8192 / 32768 resident games (its eight-fold wavefront count fills the SIMDs the lane-per-game kernel
 // leaves to one wavefront each) and 1.18x slower at 65536, where it executes 3.4x the instructions.
 static bool default_gather8(uint32_t resident_games) { return resident_games <= 32768u; }
+static bool default_hybrid(uint32_t) { return false; }
 
 template <int NW>
 struct Engine {
@@ -1227,6 +1321,13 @@ struct Engine {
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
+    // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
+    bool hybrid = false;
+    float heavy_frac = 0.15f;
+    DevBuf<uint32_t> part_ctrl, light_list, heavy_list;
+    hipStream_t hstream = nullptr;
+    hipEvent_t ev_part = nullptr, ev_heavy = nullptr;
+    uint32_t hybrid_cap() const { return S / 4 > 8 ? S / 4 : 8; }
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
@@ -1262,6 +1363,12 @@ struct Engine {
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (ev_order) hipEventDestroy(ev_order);
+        if (hstream) {
+            hipStreamSynchronize(hstream);
+            hipStreamDestroy(hstream);
+        }
+        if (ev_part) hipEventDestroy(ev_part);
+        if (ev_heavy) hipEventDestroy(ev_heavy);
         if (stream) hipStreamDestroy(stream);
     }
 
@@ -1300,14 +1407,30 @@ struct Engine {
         static_assert(sizeof(LevelO<NW>) <= (16 + 112 + sizeof(State<NW>) + 15) / 16 * 16, "slot_layout.h sizes the level stack");
         // which gather kernel walks the trees of the network path (results are identical): AR_GATHER=lane | octet
         gather8 = default_gather8(S);
-        if (const char* e = getenv("AR_GATHER")) gather8 = std::string(e) == "octet" || std::string(e) == "octet4";
-        if (const char* e = getenv("AR_GATHER")) gather8_wpe = std::string(e) == "octet4" ? 4 : 2;
+        if (const char* e = getenv("AR_GATHER")) gather8 = std::string(e).rfind("octet", 0) == 0;
+        if (const char* e = getenv("AR_GATHER")) gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : 2;
+        hybrid = default_hybrid(S);
+        if (const char* e = getenv("AR_GATHER")) hybrid = std::string(e) == "hybrid";
+        if (const char* e = getenv("AR_HEAVY_FRAC"))
+            if (atof(e) > 0.0 && atof(e) < 1.0) heavy_frac = (float)atof(e);
+        if (hybrid && need_queue) {
+            HIP_TRY(part_ctrl.alloc(8 + 2 * PART_BINS));
+            HIP_TRY(light_list.alloc(S));
+            HIP_TRY(heavy_list.alloc(S));
+            std::vector<uint32_t> init(8 + 2 * PART_BINS, 0u);
+            init[0] = 0xFFFFFFFFu;  // nobody is heavy until a histogram says so
+            HIP_TRY(hipMemcpy(part_ctrl.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipStreamCreateWithFlags(&hstream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_part, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
+        }
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
+        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = hybrid = false;  // k_gather8 addresses scratch with 32-bit offsets
         // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
         size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
         {
@@ -1483,15 +1606,34 @@ struct Engine {
             }
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used], g.stream));
         }
-        if (gather8 && gather8_wpe == 4)
+        const uint32_t* no_list = nullptr;
+        if (hybrid && groups.size() == 1) {
+            // light games one per lane, heavy games eight lanes each, side by side (k_partition)
+            const uint32_t cap = hybrid_cap();
+            hipLaunchKernelGGL(k_partition<NW>, dim3(grid(n)), dim3(64), 0, g.stream, slots.p, g.end, g.first, ready, part_ctrl.p,
+                               light_list.p, heavy_list.p, cap);
+            HIP_TRY(hipEventRecord(ev_part, g.stream));
+            HIP_TRY(hipStreamWaitEvent(hstream, ev_part, 0));
+            hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((cap + 7) / 8), dim3(64), 0, hstream, slots.p, g.end, cfg, bases(), q, qc,
+                               g.first, phase, ready, (const uint32_t*)heavy_list.p, (const uint32_t*)(part_ctrl.p + 2));
+            HIP_TRY(hipEventRecord(ev_heavy, hstream));
+            hipLaunchKernelGGL(k_gather<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q, qc,
+                               gather_rounds, 64u, g.first, phase, ready, (const uint32_t*)light_list.p,
+                               (const uint32_t*)(part_ctrl.p + 1));
+            HIP_TRY(hipStreamWaitEvent(g.stream, ev_heavy, 0));
+            hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, g.stream, part_ctrl.p, heavy_frac, cap);
+        } else if (gather8 && gather8_wpe == 3)
+            hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                               qc, g.first, phase, ready, no_list, no_list);
+        else if (gather8 && gather8_wpe == 4)
             hipLaunchKernelGGL((k_gather8<NW, 4>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                               qc, g.first, phase, ready);
+                               qc, g.first, phase, ready, no_list, no_list);
         else if (gather8)
             hipLaunchKernelGGL((k_gather8<NW, 2>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                               qc, g.first, phase, ready);
+                               qc, g.first, phase, ready, no_list, no_list);
         else
             hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg,
-                               bases(), q, qc, gather_rounds, lanes, g.first, phase, ready);
+                               bases(), q, qc, gather_rounds, lanes, g.first, phase, ready, no_list, no_list);
         if (timed_launch) {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
@@ -1530,7 +1672,8 @@ struct Engine {
     void launch_gather(bool to_queue) {
         hipLaunchKernelGGL(k_gather<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
                            to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr,
-                           gather_rounds, lanes, 0u, 0u, (uint32_t)SLOT_ACTIVE);
+                           gather_rounds, lanes, 0u, 0u, (uint32_t)SLOT_ACTIVE, (const uint32_t*)nullptr,
+                           (const uint32_t*)nullptr);
     }
     void launch_backup(bool from_queue) {
         hipLaunchKernelGGL(k_backup<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
@@ -1614,6 +1757,17 @@ struct Engine {
             }
         }
         gather_ev_used = 0;
+        if (hybrid && part_ctrl.p && getenv("AR_PART_DEBUG")) {
+            static int seen = 0;
+            if ((seen++ % 16) == 8) {
+                uint32_t h[8 + 2 * PART_BINS];
+                if (hipMemcpy(h, part_ctrl.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+                    fprintf(stderr, "[ar part] cut %u light %u heavy %u | rounds/8 histogram:", h[0], h[3], h[4]);
+                    for (int b = 0; b < PART_BINS; ++b) fprintf(stderr, " %u", h[8 + PART_BINS + b]);
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
         for (int c = 0; c < POOL_CLASSES; ++c)
             if (pool.n[c] && h_counts.p[5 + c] < pool_low[c]) pool_low[c] = h_counts.p[5 + c];
@@ -2063,7 +2217,7 @@ struct SelfPlaySession : SessionBase {
         }
         if (const char* e = getenv("AR_LANES_PER_WAVE"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
-        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = false;  // the round limit parks lane state: lane kernel only
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.hybrid = false;  // the round limit parks lane state: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();

@@ -48,6 +48,33 @@ struct alignas(16) LevelO {
     State<NW> saved;
 };
 
+// what an octet touches rarely lives in LDS (coherent inside the wavefront, no registers): the game's random
+// stream -- only tie breaks draw from it, search.rs:511-532 -- and the root position, read once per pick
+template <int NW>
+struct OctShared {
+    Rng rng;
+    State<NW> root_st;
+};
+
+// one game's memory as the octet addresses it: two 64-bit arena pointers, everything else as 32-bit offsets
+// from kernel-argument bases (scratch block, maze pool), so the address arithmetic stays in scalar registers
+template <int NW>
+struct OctMem {
+    NodeStats* stats;
+    NodeKids* kids;
+    unsigned char* scratch;  // uniform base of all games' scratch
+    const uint8_t* maze;     // uniform base of the maze pool
+    uint32_t s_off;          // this game's scratch block
+    uint32_t maze_off;       // this game's cost table
+    uint32_t proc_off, coll_off, levels_off, leaf_off;  // SlotLayout offsets (uniform)
+    uint32_t coll_cap, max_depth;
+    __device__ const uint8_t* cost() const { return maze + maze_off; }
+    __device__ ProcEntry* proc() const { return (ProcEntry*)(scratch + (s_off + proc_off)); }
+    __device__ CollEntry* coll() const { return (CollEntry*)(scratch + (s_off + coll_off)); }
+    __device__ LevelO<NW>* levels() const { return (LevelO<NW>*)(scratch + (s_off + levels_off)); }
+    __device__ State<NW>* leaves() const { return (State<NW>*)(scratch + (s_off + leaf_off)); }
+};
+
 template <int NW>
 struct Oct {
     // ---- replicated ----
@@ -56,13 +83,13 @@ struct Oct {
     long long left;
     uint32_t depth, node, mask, omap0, omap1, pick_mv;
     bool have_pick;
-    State<NW> work, root_st;
+    State<NW> work;  // position at the current node
     uint32_t alloc_left;
     uint32_t n1, n2;  // outcomes of the node being allocated
-    Rng rng;
     // mirrored slot fields
     uint32_t hi, cap, root, node_count, n_proc, n_coll, b_nn, b_term, b_coll, error, batch_active;
     uint32_t d_new, d_visits;  // new nodes / node records entered in this gather
+    uint32_t rounds;           // rounds of this gather
     // ---- per octet lane ----
     float sc[2], util[2], num[2];  // lane i: outcome i of player 0 / 1
     uint32_t ns[2], add[2], nif0[2], forced;
@@ -71,10 +98,11 @@ struct Oct {
 
 __device__ inline uint32_t sel4(const uint32_t* a, uint32_t c) { return c == 0 ? a[0] : c == 1 ? a[1] : c == 2 ? a[2] : a[3]; }
 
-// search.rs:500-554 on five scores that every lane holds; `util_mine`, `num_mine`, `ns_mine` are this lane's own
-// outcome. Returns the chosen outcome and, in lane `best`, the visits until the best changes (other lanes' value is
-// meaningless and is replaced by lane best's through oct_pick by the caller).
-__device__ inline void best_of5(const float* s, uint32_t n, Rng& rng, uint32_t& best_out, float& second_out) {
+// search.rs:500-532 on five scores that every lane holds: best and second-best in outcome order, then the tie
+// pass. The random stream is only fetched (from LDS) when some outcome ties with the best one -- exactly the
+// cases in which the reference draws.
+template <int NW>
+__device__ inline void best_of5(const float* s, uint32_t n, OctShared<NW>& sh, uint32_t& best_out, float& second_out) {
     const float NEG_INF = -__builtin_inff();
     uint32_t best = 0;
     float best_score = NEG_INF, second = NEG_INF;
@@ -91,13 +119,22 @@ __device__ inline void best_of5(const float* s, uint32_t n, Rng& rng, uint32_t& 
             }
         }
     }
-    uint32_t ties = 1;
+    bool any_tie = false;
 #pragma unroll
-    for (uint32_t i = 0; i < 5; ++i) {
-        if (i < n && i != best && fabsf(s[i] - best_score) < 1e-12f) {
-            ties += 1;
-            if (rng_below(rng, ties) == 0) best = i;
+    for (uint32_t i = 0; i < 5; ++i) any_tie = any_tie || (i < n && i != best && fabsf(s[i] - best_score) < 1e-12f);
+    if (any_tie) {
+        Rng rng = sh.rng;
+        uint32_t ties = 1;
+#pragma unroll
+        for (uint32_t i = 0; i < 5; ++i) {
+            if (i < n && i != best && fabsf(s[i] - best_score) < 1e-12f) {
+                ties += 1;
+                if (rng_below(rng, ties) == 0) best = i;
+            }
         }
+        // every lane stores the (identical) new state: each thread then reads back what it wrote itself, so the
+        // compiler cannot keep a stale copy in registers for the lanes that would otherwise only read
+        sh.rng = rng;
     }
     best_out = best;
     second_out = second;
@@ -118,15 +155,15 @@ __device__ inline uint32_t vtc_of(float util, float num, uint32_t ns, float seco
 
 // One round of an octet's gather: the same decisions in the same order as gather_round (dev_search.h).
 template <int NW>
-__device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<NW>& m, const SearchCfg& cfg, uint32_t ol) {
+__device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Board& board, const OctMem<NW>& m,
+                                     const SearchCfg& cfg, uint32_t ol) {
     if (o.done) return;
+    o.rounds += 1;
     if (o.alloc_left == 0) {
-        const State<NW> before = o.work;
-        LevelO<NW>* levels = (LevelO<NW>*)m.levels;
         if (o.mask == 0 && o.depth > 0) {
             // level exhausted: backtrack (search.rs:728-734)
             o.depth -= 1;
-            const LevelO<NW>& L = levels[o.depth];
+            const LevelO<NW>& L = m.levels()[o.depth];
             o.node = L.node;
             o.mask = L.mask;
             o.omap0 = L.omap0;
@@ -148,7 +185,7 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
             uint32_t rec = NIL, visits_in = 0;
             bool from_pick = false;
             uint32_t emit_node = NIL, emit_kind = PROC_NONE, coll_mv = 0;
-            bool restore = false;
+            State<NW> pos;  // the position at the node that is looked at (the current node's stays in o.work)
             if (o.mask == 0) {
                 // search.rs:981-999 outer gather loop around pick_nodes_to_extend
                 if (o.have_pick) {
@@ -165,7 +202,7 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                 if (o.batch - o.n_proc < budget) budget = o.batch - o.n_proc;
                 o.pick_mv = 0;
                 o.have_pick = true;
-                o.work = o.root_st;
+                pos = sh.root_st;
                 rec = o.root;
                 visits_in = budget;
                 from_pick = true;
@@ -175,7 +212,8 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                 const uint32_t k = oct_pick(sel4(o.vtp, idx & 3u), idx >> 2);
                 const uint32_t o1 = idx / 5, o2 = idx % 5;
                 float r1, r2;
-                st_step(board, m.cost, o.work, outcome_action(o.omap0, o1), outcome_action(o.omap1, o2), r1, r2);
+                pos = o.work;
+                st_step(board, m.cost(), pos, outcome_action(o.omap0, o1), outcome_action(o.omap1, o2), r1, r2);
                 const uint32_t child = oct_pick(sel4(o.kid, idx & 3u), idx >> 2);
                 if (child == NIL) {
                     // new leaf: shell creation + claim are stores only (tree.rs:107-148, search.rs:675-701)
@@ -183,31 +221,29 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                         o.error = 3;
                     } else {
                         const uint32_t nid = o.hi++;
-                        const bool over = st_over(board, o.work);
-                        NodeH0 h0;
-                        h0.v1 = 0.0f;
-                        h0.v2 = 0.0f;
-                        h0.visits = 0;
-                        h0.nif = 1;  // try_start_score_update on a fresh node
-                        NodeH1 h1;
-                        h1.scale = (float)(o.work.remaining > 1 ? o.work.remaining : 1);
-                        h1.r1 = r1;
-                        h1.r2 = r2;
-                        h1.parent = o.node;
-                        NodeH2 h2;
-                        uint32_t nn1, nn2;
-                        pack_outcomes(eff_actions(m.cost, o.work.p1, o.work.m1), h2.omap[0], nn1);
-                        pack_outcomes(eff_actions(m.cost, o.work.p2, o.work.m2), h2.omap[1], nn2);
-                        h2.meta = nn1 | (nn2 << 8) | (o1 << 16) | (o2 << 24);
-                        h2.terminal = over ? 1u : 0u;
-                        // one 16-byte group per lane: groups 0..7, then 8..12; the child table's seven groups
+                        const bool over = st_over(board, pos);
+                        // one 16-byte group per lane: the edge groups 0..9 are zero (prior 0, q 0, visits 0, nif 0),
+                        // groups 10..12 the headers; the child table's seven groups are all NIL
+                        uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0;
+                        if (ol == 2) {  // h0: v1 0, v2 0, visits 0, nif 1 (try_start_score_update on a fresh node)
+                            g1.w = 1u;
+                        } else if (ol == 3) {  // h1: scale, edge rewards, parent
+                            g1.x = __float_as_uint((float)(pos.remaining > 1 ? pos.remaining : 1));
+                            g1.y = __float_as_uint(r1);
+                            g1.z = __float_as_uint(r2);
+                            g1.w = o.node;
+                        } else if (ol == 4) {  // h2: outcome maps, counts, terminal flag
+                            uint32_t nn1, nn2, om0, om1;
+                            pack_outcomes(eff_actions(m.cost(), pos.p1, pos.m1), om0, nn1);
+                            pack_outcomes(eff_actions(m.cost(), pos.p2, pos.m2), om1, nn2);
+                            g1.x = om0;
+                            g1.y = om1;
+                            g1.z = nn1 | (nn2 << 8) | (o1 << 16) | (o2 << 24);
+                            g1.w = over ? 1u : 0u;
+                        }
                         uint4* S = (uint4*)&m.stats[nid];
-                        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);  // Edge{prior 0, q 0, visits 0, nif 0}
-                        S[ol] = zero;
-                        if (ol < 2) S[8 + ol] = zero;
-                        else if (ol == 2) *(NodeH0*)&S[10] = h0;
-                        else if (ol == 3) *(NodeH1*)&S[11] = h1;
-                        else if (ol == 4) *(NodeH2*)&S[12] = h2;
+                        S[ol] = g0;
+                        if (ol < 5) S[8 + ol] = g1;
                         if (ol < 7) ((uint4*)&m.kids[nid])[ol] = make_uint4(NIL, NIL, NIL, NIL);
                         if (ol == 0) m.kids[o.node].c[idx] = nid;
                         o.node_count += 1;
@@ -216,7 +252,6 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                         emit_kind = over ? PROC_TERMINAL : PROC_EVAL;
                         coll_mv = k > 1 ? k - 1 : 0;
                     }
-                    restore = true;
                 } else {
                     rec = child;
                     visits_in = k;
@@ -242,7 +277,7 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                     // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
                     emit_node = rec;
                     if (!(a.visits == 0 && a.nif > 0)) {  // try_start_score_update
-                        const bool term = c.terminal != 0 || st_over(board, o.work);
+                        const bool term = c.terminal != 0 || st_over(board, pos);
                         if (ol == 0) {
                             m.stats[rec].h0.nif = a.nif + 1;
                             if (term && a.visits == 0) m.stats[rec].h2.terminal = 1;
@@ -252,26 +287,25 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                     } else {
                         coll_mv = visits_in;
                     }
-                    restore = true;
                 } else if (!from_pick && o.depth >= m.max_depth) {
                     o.error = 4;
-                    restore = true;
                 } else {
                     // visited interior node: route the visits through it (search.rs:639 / :707-725)
                     if (ol == 0) m.stats[rec].h0.nif = a.nif + visits_in;
                     if (!from_pick && o.mask != 0) {  // siblings still wait: keep the parent level for the way back
-                        LevelO<NW>& L = levels[o.depth];
+                        LevelO<NW>& L = m.levels()[o.depth];
                         if (ol == 0) {
                             L.node = o.node;
                             L.mask = o.mask;
                             L.omap0 = o.omap0;
                             L.omap1 = o.omap1;
-                            L.saved = before;
+                            L.saved = o.work;
                         }
                         if (ol < 7) *(uint4*)&L.vtp[4 * ol] = make_uint4(o.vtp[0], o.vtp[1], o.vtp[2], o.vtp[3]);
                         o.depth += 1;
                     }
                     if (from_pick) o.depth = 0;
+                    o.work = pos;
                     // build_gather_level set-up (search.rs:742-774): this lane's outcome for both players
                     const uint32_t cv = a.visits > 0 ? a.visits - 1 : 0;
                     const uint32_t n1 = meta_n(c.meta, 0), n2 = meta_n(c.meta, 1);
@@ -339,11 +373,11 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                         ProcEntry pe;
                         pe.node = emit_node;
                         pe.kind = emit_kind;
-                        m.proc[i] = pe;
+                        m.proc()[i] = pe;
                     }
                     if (emit_kind == PROC_EVAL) {
                         const uint32_t j = o.b_nn++;
-                        if (ol == 1) m.leaf_local[j] = o.work;
+                        if (ol == 1) m.leaves()[j] = pos;
                     } else {
                         o.b_term += 1;
                     }
@@ -358,35 +392,34 @@ __device__ inline void gather8_round(Oct<NW>& o, const Board& board, const Mem<N
                         CollEntry ce;
                         ce.node = emit_node;
                         ce.mv = coll_mv;
-                        m.coll[o.n_coll] = ce;
+                        m.coll()[o.n_coll] = ce;
                     }
                     o.n_coll += 1;
                 }
             }
-            if (restore) o.work = before;
         }
     }
     if (o.alloc_left > 0) {
         for (uint32_t it = 0; it < cfg.alloc_per_round && o.alloc_left > 0; ++it) {  // search.rs:775-798, no memory traffic
-            float s1[5], s2[5];
-            s1[0] = oct_getf<0>(o.sc[0]);
-            s2[0] = oct_getf<0>(o.sc[1]);
-            s1[1] = oct_getf<1>(o.sc[0]);
-            s2[1] = oct_getf<1>(o.sc[1]);
-            s1[2] = oct_getf<2>(o.sc[0]);
-            s2[2] = oct_getf<2>(o.sc[1]);
-            s1[3] = oct_getf<3>(o.sc[0]);
-            s2[3] = oct_getf<3>(o.sc[1]);
-            s1[4] = oct_getf<4>(o.sc[0]);
-            s2[4] = oct_getf<4>(o.sc[1]);
             uint32_t b1 = 0, b2 = 0, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu;
-            float sec1, sec2;
             if (o.n1 > 1) {  // (a single outcome never changes: search.rs:470-472)
-                best_of5(s1, o.n1, o.rng, b1, sec1);
+                float s1[5], sec1;
+                s1[0] = oct_getf<0>(o.sc[0]);
+                s1[1] = oct_getf<1>(o.sc[0]);
+                s1[2] = oct_getf<2>(o.sc[0]);
+                s1[3] = oct_getf<3>(o.sc[0]);
+                s1[4] = oct_getf<4>(o.sc[0]);
+                best_of5(s1, o.n1, sh, b1, sec1);
                 c1 = oct_pick(vtc_of(o.util[0], o.num[0], o.ns[0], sec1), b1);
             }
             if (o.n2 > 1) {
-                best_of5(s2, o.n2, o.rng, b2, sec2);
+                float s2[5], sec2;
+                s2[0] = oct_getf<0>(o.sc[1]);
+                s2[1] = oct_getf<1>(o.sc[1]);
+                s2[2] = oct_getf<2>(o.sc[1]);
+                s2[3] = oct_getf<3>(o.sc[1]);
+                s2[4] = oct_getf<4>(o.sc[1]);
+                best_of5(s2, o.n2, sh, b2, sec2);
                 c2 = oct_pick(vtc_of(o.util[1], o.num[1], o.ns[1], sec2), b2);
             }
             uint32_t k = o.alloc_left;

@@ -144,6 +144,7 @@ struct alignas(128) Slot {
     MoveResult last;  // result of the last finished search
     uint32_t error;   // non-zero: internal capacity violation (bug guard)
     uint32_t gather_pending;  // 1: a gather was cut off at the round limit, its lane state is in Mem::glane
+    uint32_t g_rounds;        // rounds the game's last complete gather took (scheduling hint: which kernel walks it next)
 };
 
 // resolved addresses of one game's memory (built per kernel from kernel arguments + slot offsets)
@@ -838,13 +839,14 @@ AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg&
         }
     }
 #endif
-    (void)my_rounds;
     if (!ok) return GATHER_STALLED;
     if (g.state != G_DONE) {
         *parked = g;
         s.gather_pending = 1;
+        s.g_rounds += my_rounds;
         return GATHER_PENDING;
     }
+    s.g_rounds = (s.gather_pending ? s.g_rounds : 0u) + my_rounds;
     s.gather_pending = 0;
     return GATHER_COMPLETE;
 }
@@ -1310,6 +1312,7 @@ AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     s.batch_active = 0;
     s.error = 0;
     s.gather_pending = 0;
+    s.g_rounds = 0;
     s.remaining = cfg.n_sims;
     make_root(s, m);
     if (!s.single_search && st_over(s.board, s.st)) s.status = SLOT_DONE;  // while !check_game_over()

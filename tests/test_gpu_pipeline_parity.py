@@ -76,15 +76,16 @@ def _note(line):
         pass
 
 
-@pytest.mark.parametrize("name,blob,sims,search,n_oracle", [
-    ("config3_mlp", "mlp_7x7_h256", 1897, TUNED, 3),             # 7x7, PyRatMLP h256, 7x7_rust_tuned
-    ("config4_symmetric", "symmetric_7x7_h256", 2693, STRONG, 2),  # SymmetricMLP h256, 7x7_rust_strong
-    ("config5_cnn", "cnn_gpool_7x7_c64", 4096, TUNED, 2),         # CNN + global pooling c64, 4096 sims
+@pytest.mark.parametrize("name,blob,sims,search,n_games,n_oracle", [
+    ("config3_mlp", "mlp_7x7_h256", 1897, TUNED, 96, 3),             # 7x7, PyRatMLP h256, 7x7_rust_tuned
+    ("config4_symmetric", "symmetric_7x7_h256", 2693, STRONG, 96, 2),  # SymmetricMLP h256, 7x7_rust_strong
+    # CNN + global pooling c64, 4096 sims: a 50-turn game is 12 800 device steps, so only two slots are refilled
+    ("config5_cnn", "cnn_gpool_7x7_c64", 4096, TUNED, 66, 2),
 ])
-def test_network_selfplay_records_bit_exact(name, blob, sims, search, n_oracle):
+def test_network_selfplay_records_bit_exact(name, blob, sims, search, n_games, n_oracle):
     from alpharat_amd.sampling import rust_self_play
 
-    n_games, resident = 96, 64
+    resident = 64
     games = {}
     t0 = time.perf_counter()
     stats = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=n_games, simulations=sims,
@@ -98,7 +99,7 @@ def test_network_selfplay_records_bit_exact(name, blob, sims, search, n_oracle):
     ev = HipEvaluator(GOLD / f"{blob}.arnet", 7, 7, 50)
     cfg = O.make_config(**search)
     # a game that started in a refilled slot, the first game of the run, and the last one
-    for i in [70, 0, n_games - 1][:n_oracle]:
+    for i in [n_games - 1, 0, 70][:n_oracle]:
         t0 = time.perf_counter()
         want = O.play_game(O.Game(7, 7, 50).random_cheese(10, True, i), cfg, sims, 16, 0xA1FA0000 + i, backend=4,
                            net=ev.backend, game_index=i)

@@ -10,16 +10,24 @@ from alpharat_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = _lib.PKG / "libalpharat_hip_stats.so"
 import bench  # noqa: E402
-from alpharat_amd.sampling import rust_self_play  # noqa: E402
+from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession  # noqa: E402
 
 L = _lib.load()
-games = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-resident = int(sys.argv[2]) if len(sys.argv) > 2 else games
+resident = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 3072   # batch steps before the measured window (steady state)
+window = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 blob = bench.make_mlp_blob(ROOT / "gpurun_out" / "bench_mlp_7x7_h256.arnet")
-st = rust_self_play(**bench.GAME, num_games=games, simulations=bench.SIMS, batch_size=bench.BATCH, output_dir=None,
-                    weights_path=str(blob), seed=0, concurrent_games=resident, **bench.SEARCH)
-out = (C.c_ulonglong * 136)()
+search, sims, batch, _ = bench.WORKLOADS["mlp"]
 L.ar_debug_gather_hist.argtypes = [C.c_void_p]
+L.ar_debug_gather_clk.argtypes = [C.c_void_p]
+out = (C.c_ulonglong * 136)()
+clk = (C.c_ulonglong * 128)()
+with SelfPlaySession(**bench.GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
+                     weights_path=str(blob), seed=0, concurrent_games=resident, **search) as s:
+    s.step(warm)
+    L.ar_debug_gather_hist(out)  # (reading resets the counters)
+    L.ar_debug_gather_clk(clk)
+    st = s.step(window)
 L.ar_debug_gather_hist(out)
 o = list(out)
 lanes, waves, paths = o[:64], o[64:128], o[128:136]
@@ -44,8 +52,6 @@ tot = sum(paths[:5]) + paths[6] + paths[7]
 print("lane-rounds by path:")
 for n, c in zip(names, paths):
     print(f"   {n:<30} {c:>14}  {100.0 * c / max(tot, 1):6.2f}% of lane-rounds")
-clk = (C.c_ulonglong * 128)()
-L.ar_debug_gather_clk.argtypes = [C.c_void_p]
 L.ar_debug_gather_clk(clk)
 clk = list(clk)
 print("gather loop wall clock (100 MHz ticks -> us) by wavefront max rounds:")
