@@ -59,7 +59,7 @@ WORKLOADS = {
             "4096 sims (tuned constants, batch 16, noise 0.25), PyRatCNN c64 res,res,gpool(32) random weights"),
 }
 # sources whose change invalidates a committed PMC traffic measurement of the tree kernels
-TRAFFIC_SOURCES = ("dev_search.h", "dev_engine.h", "dev_rng.h", "slot_layout.h", "alpharat_hip.hip")
+TRAFFIC_SOURCES = ("dev_search.h", "dev_gather8.h", "dev_engine.h", "dev_rng.h", "slot_layout.h", "alpharat_hip.hip")
 
 
 def kernel_source_hash() -> str:
@@ -159,9 +159,11 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-steps", type=int, default=1024,
-                    help="passes of the hot path (gather -> evaluate -> backup) over all resident games per step")
-    ap.add_argument("--resident", type=int, default=65536, help="games resident on each GPU (one lane each)")
+    ap.add_argument("--batch-steps", type=int, default=0,
+                    help="passes of the hot path (gather -> evaluate -> backup) over all resident games per step "
+                         "(default: 1024 for mlp / uniform, 128 for symmetric, 64 for cnn)")
+    ap.add_argument("--resident", type=int, default=0,
+                    help="games resident on each GPU (default: 65536; 16384 for cnn)")
     ap.add_argument("--evaluator", choices=sorted(WORKLOADS), default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="bound of the CPU baseline sample")
@@ -203,6 +205,10 @@ def main() -> int:
     from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession
 
     search, sims, batch, workload = WORKLOADS[args.evaluator]
+    if args.batch_steps <= 0:
+        args.batch_steps = {"symmetric": 128, "cnn": 64}.get(args.evaluator, 1024)
+    if args.resident <= 0:
+        args.resident = 16384 if args.evaluator == "cnn" else 65536
     weights = weights_for(args.evaluator, rank)
     if dist is not None:
         dist.barrier()
