@@ -87,11 +87,17 @@ struct ArenaPool {
     uint32_t* ret_n;                  // [POOL_CLASSES]
 };
 
+// The cost tables are read once or twice in every round of a gather (the step into the next child), in front of the
+// round's record fetch: with one maze shared by all games (open mazes) -- or a handful, in batched searches -- the
+// whole pool is copied into LDS at kernel start, which takes a dependent L2 round trip out of every round.
+enum { MAZE_STAGE_BYTES = 4096 };
+
 // the three bases every tree kernel receives; all per-game addresses derive from them
 struct Bases {
     unsigned char* arena;    // pool of first arenas; grown arenas are addressed relative to it too
     unsigned char* scratch;  // S x layout.total
     const uint8_t* maze;     // cost tables
+    uint32_t maze_stage;     // bytes of the whole maze pool when it is small enough to sit in LDS (else 0)
     SlotLayout L;
     uint32_t cap0;           // nodes per first arena
     ArenaPool pool;
@@ -235,6 +241,11 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
                                                uint32_t accept_ready, const uint32_t* list, const uint32_t* list_n) {
     // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64);
     // with a `list` (k_partition): the games list[0 .. *list_n)
+    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
+    if (B.maze_stage) {
+        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
+        __syncthreads();
+    }
     if (threadIdx.x >= lanes) return;
     uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (list != nullptr) {
@@ -249,7 +260,8 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
     }
     Slot<NW> s = slots[i];
     s.status = SLOT_ACTIVE;
-    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    if (B.maze_stage) m.cost = (const uint8_t*)lds_maze + s.board.maze_off;
     // a batch that was already gathered and still waits for its backup is left alone
     const int got = s.batch_active ? GATHER_PENDING : gather_machine_limited(s, m, cfg, EVAL_STORE, max_rounds);
     if (got == GATHER_COMPLETE && queue != nullptr && s.b_nn > 0) {
@@ -277,6 +289,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
                                                 const uint32_t* list_n) {
     const uint32_t ol = threadIdx.x & 7u;
     uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
+    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
     if (list != nullptr) {  // (k_partition) the games list[0 .. *list_n)
         uint32_t n_list = *list_n;
         if (n_list > gridDim.x * 8u) n_list = gridDim.x * 8u;  // (k_partition caps the list at the grid's size)
@@ -296,6 +309,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     m.kids = (NodeKids*)(B.arena + S.kids_off);
     m.scratch = B.scratch;
     m.maze = B.maze;
+    if (B.maze_stage) {
+        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
+        m.maze = (const uint8_t*)lds_maze;  // (the barrier below, in front of the rounds, orders these writes)
+    }
     m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
     m.maze_off = S.board.maze_off;
     m.proc_off = (uint32_t)B.L.proc_off;
@@ -1265,7 +1282,9 @@ struct ArenaHold {
 // section 7, profiles/r02_gather_ab.md) the eight-lanes-per-game kernel is 1.9x / 1.7x / 1.07x faster per launch at
 // 1024 / 8192 / 32768 resident games (its eight-fold wavefront count fills the SIMDs the lane-per-game kernel
 // leaves to one wavefront each) and 1.18x slower at 65536, where it executes 3.4x the instructions.
-static bool default_gather8(uint32_t resident_games) { return resident_games <= 32768u; }
+static bool default_gather8(uint32_t) { return true; }
+// its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
+static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
 static bool default_hybrid(uint32_t) { return false; }
 
 template <int NW>
@@ -1319,6 +1338,7 @@ struct Engine {
     DevBuf<unsigned long long> cache_counters;
     ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
+    uint32_t backup_lanes = 64;  // games per wavefront in the network path's k_backup (AR_BACKUP_LANES)
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
@@ -1377,6 +1397,7 @@ struct Engine {
         b.arena = arena.p;
         b.scratch = scratch.p;
         b.maze = maze.p;
+        b.maze_stage = (!per_slot_maze && maze.n > 0 && maze.n <= MAZE_STAGE_BYTES && maze.n % 4 == 0) ? (uint32_t)maze.n : 0u;
         b.L = L;
         b.cap0 = cap0;
         b.pool = pool;
@@ -1407,8 +1428,11 @@ struct Engine {
         static_assert(sizeof(LevelO<NW>) <= (16 + 112 + sizeof(State<NW>) + 15) / 16 * 16, "slot_layout.h sizes the level stack");
         // which gather kernel walks the trees of the network path (results are identical): AR_GATHER=lane | octet
         gather8 = default_gather8(S);
+        gather8_wpe = default_gather8_wpe(S);
         if (const char* e = getenv("AR_GATHER")) gather8 = std::string(e).rfind("octet", 0) == 0;
-        if (const char* e = getenv("AR_GATHER")) gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : 2;
+        if (const char* e = getenv("AR_GATHER"))
+            if (std::string(e).rfind("octet", 0) == 0)
+                gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : std::string(e) == "octet2" ? 2 : gather8_wpe;
         hybrid = default_hybrid(S);
         if (const char* e = getenv("AR_GATHER")) hybrid = std::string(e) == "hybrid";
         if (const char* e = getenv("AR_HEAVY_FRAC"))
@@ -1653,8 +1677,8 @@ struct Engine {
         } else if (int rc = net_forward_queue<NW>(net, q, qc, n_max, slots.p, maze.p, ev, g.stream)) {
             return rc;
         }
-        hipLaunchKernelGGL(k_backup<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(),
-                           zig.p, ev, lanes, g.first, phase);
+        hipLaunchKernelGGL(k_backup<NW>, dim3((n + backup_lanes - 1) / backup_lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg,
+                           bases(), zig.p, ev, backup_lanes, g.first, phase);
         if (side) {
             HIP_TRY(hipEventRecord(g.backed_up, g.stream));
             HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
@@ -2167,6 +2191,8 @@ struct SelfPlaySession : SessionBase {
             if (hipSetDevice(device) != hipSuccess) return fail(AR_E_DEVICE, "hipSetDevice failed");
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
             free_b += arena_cached_bytes(device);  // the block kept from the previous call is ours to reuse
+            if (const char* e = getenv("AR_MEM_FRACTION"))  // several processes on one device (bench rehearsals): each
+                if (atof(e) > 0.0 && atof(e) <= 1.0) free_b = (size_t)((double)free_b * atof(e));  // takes its share
             const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
                                     Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr);
             const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
@@ -2216,7 +2242,9 @@ struct SelfPlaySession : SessionBase {
             if (int rc = eng.make_groups(ng)) return rc;
         }
         if (const char* e = getenv("AR_LANES_PER_WAVE"))
-            if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = (uint32_t)atoi(e);
+            if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = eng.backup_lanes = (uint32_t)atoi(e);
+        if (const char* e = getenv("AR_BACKUP_LANES"))
+            if (atoi(e) >= 1 && atoi(e) <= 64) eng.backup_lanes = (uint32_t)atoi(e);
         if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.hybrid = false;  // the round limit parks lane state: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);

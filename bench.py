@@ -196,6 +196,7 @@ def main() -> int:
         backend = os.environ.get("AR_BENCH_BACKEND", "nccl")
         if "AR_BENCH_DEVICE" in os.environ:
             local_rank = int(os.environ["AR_BENCH_DEVICE"])
+            os.environ.setdefault("AR_MEM_FRACTION", f"{0.8 / world:.3f}")  # the ranks share one device's memory
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist_mod.init_process_group(backend)
