@@ -29,6 +29,7 @@
 #include "npz_writer.h"
 #include "slot_layout.h"
 #include "dev_gather8.h"
+#include "dev_backup16.h"
 #include "zig_norm_tables.inc"
 
 using namespace ar;
@@ -490,6 +491,40 @@ __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
     const EvalOut* ev = ev_queue ? ev_queue + s.eval_base : m.ev_local;
     if (backup_machine(s, m, cfg, ev, zt)) finish_move(s, m, cfg);
+    s.status = tag_status(s.status, phase);
+    slots[i] = s;
+}
+
+// The backup with sixteen lanes per game (dev_backup16.h): ceil(n / 4) blocks of 64 threads, dynamic LDS = 64 paths
+// of `path_cap` steps. Ends with batch_end; a search that is complete is left in the state (ACTIVE, no batch,
+// remaining == 0) for k_finish.
+template <int NW>
+__global__ void __launch_bounds__(64) k_backup16(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                                 const ZigTables* zt, const EvalOut* ev_queue, uint32_t first,
+                                                 uint32_t path_cap) {
+    extern __shared__ PathStep lds_path[];
+    const uint32_t w = threadIdx.x & 15u;
+    const uint32_t i = first + blockIdx.x * 4u + (threadIdx.x >> 4);
+    bool active = i < n_slots && slots[i].status == SLOT_ACTIVE && slots[i].batch_active != 0;
+    const uint32_t ii = i < n_slots ? i : first;
+    Slot<NW>& S = slots[ii];
+    const Mem<NW> m = resolve_mem<NW>(S, B.arena, B.scratch, ii, B.L, B.maze);
+    active = active && backup16_wants(S, m, cfg);
+    const EvalOut* ev = ev_queue ? ev_queue + S.eval_base : m.ev_local;
+    (void)zt;
+    backup16<NW>(active, S, m, cfg, ev, lds_path + (size_t)threadIdx.x * PATH_LDS_STEPS, path_cap, w);
+    if (active && w == 0) batch_end(S);
+}
+// the end of a move (selfplay.rs:538-565 up to the tree reuse) for the games whose search k_backup16 completed
+template <int NW>
+__global__ void __launch_bounds__(64) k_finish(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B, uint32_t first,
+                                               uint32_t phase) {
+    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    if (slots[i].status != SLOT_ACTIVE || slots[i].batch_active != 0 || slots[i].remaining != 0) return;
+    Slot<NW> s = slots[i];
+    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
+    finish_move(s, m, cfg);
     s.status = tag_status(s.status, phase);
     slots[i] = s;
 }
@@ -1339,6 +1374,7 @@ struct Engine {
     ArenaPool pool = {};            // overflow blocks handed out by the kernels themselves
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
     uint32_t backup_lanes = 64;  // games per wavefront in the network path's k_backup (AR_BACKUP_LANES)
+    bool backup16 = false;       // network path: the sixteen-lanes-per-game backup (k_backup16 + k_finish) instead of k_backup
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
@@ -1429,6 +1465,10 @@ struct Engine {
         // which gather kernel walks the trees of the network path (results are identical): AR_GATHER=lane | octet
         gather8 = default_gather8(S);
         gather8_wpe = default_gather8_wpe(S);
+        // which backup kernel (results are identical): AR_BACKUP=lane | group; the group kernel keeps 64 paths in LDS
+        // (the deep part of its paths lives in the level-stack scratch: 16 lanes x path_cap steps must fit there)
+        backup16 = (size_t)16 * (L.max_depth + 2) * sizeof(PathStep) <= (size_t)L.max_depth * (16 + 112 + sizeof(State<NW>));
+        if (const char* e = getenv("AR_BACKUP")) backup16 = backup16 && std::string(e) != "lane";
         if (const char* e = getenv("AR_GATHER")) gather8 = std::string(e).rfind("octet", 0) == 0;
         if (const char* e = getenv("AR_GATHER"))
             if (std::string(e).rfind("octet", 0) == 0)
@@ -1677,8 +1717,18 @@ struct Engine {
         } else if (int rc = net_forward_queue<NW>(net, q, qc, n_max, slots.p, maze.p, ev, g.stream)) {
             return rc;
         }
-        hipLaunchKernelGGL(k_backup<NW>, dim3((n + backup_lanes - 1) / backup_lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg,
-                           bases(), zig.p, ev, backup_lanes, g.first, phase);
+        if (backup16) {
+            const uint32_t path_cap = L.max_depth + 2;
+            hipLaunchKernelGGL(k_backup16<NW>, dim3((n + 3) / 4), dim3(64), (size_t)64 * PATH_LDS_STEPS * sizeof(PathStep),
+                               g.stream, slots.p, g.end, cfg, bases(), zig.p, ev, g.first, path_cap);
+            hipLaunchKernelGGL(k_finish<NW>, dim3(grid(n)), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), g.first, phase);
+            // (fresh roots that draw Dirichlet noise were left alone above; k_finish ignores a slot with a batch pending)
+            if (cfg.noise_epsilon > 0.0f)
+                hipLaunchKernelGGL(k_backup<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), zig.p,
+                                   ev, 64u, g.first, phase);
+        } else
+            hipLaunchKernelGGL(k_backup<NW>, dim3((n + backup_lanes - 1) / backup_lanes), dim3(64), 0, g.stream, slots.p, g.end,
+                               cfg, bases(), zig.p, ev, backup_lanes, g.first, phase);
         if (side) {
             HIP_TRY(hipEventRecord(g.backed_up, g.stream));
             HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
