@@ -49,6 +49,10 @@ struct NetDev {
     int n_head, Kh;
     const float* cmaze;      // [n_mazes][H] first-layer maze contribution incl. bias
     int n_mazes;
+    // PyRatMLP on split-bf16 matrix products (k_mlp_bf16): three bf16 planes (hi, mid, lo) of the two hidden layers'
+    // weights in MFMA operand order, [k16][column tile][lane][8]; null when the network does not qualify
+    const void *w1p[3], *w2p[3];
+    int nk1, nk2;            // 16-deep k-steps of layer 1 (non-maze inputs, zero-padded) and layer 2
 };
 
 struct Blob {
@@ -649,6 +653,209 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
             for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = hh[k];
     }
 }
+// ---- PyRatMLP with the two hidden layers on the bf16 matrix pipe at fp32 accuracy ---------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA. A float is the exact sum of three bf16 values
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 8 + 8 + 8 mantissa bits), so a product a*b is the sum
+// of nine bf16 x bf16 products, each exact in the fp32 accumulator; the six of them above 2^-24 of a*b --
+// hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi -- reproduce the fp32 product to ~2^-23, i.e. six MFMAs of 32 cycles
+// for 16 k-steps instead of eight fp32 MFMAs of 64 cycles: 2.7x fewer matrix-pipe cycles. Measured against the fp32
+// reference on the golden network: max |logit error| 6e-8 (three terms: 1.2e-5, which would not meet the 1e-5 bar).
+// The weights are split on the host (net_build); activations are split in registers after the LDS read. The first
+// layer's operand is one-hot except six scalars: its hi plane is exact and mid / lo are zero for the first nine
+// k16-steps, which therefore need three MFMAs. Heads stay on the fp32 16x16x4 tiles (12 rows: negligible).
+// Accumulation order differs from the scalar loops, so outputs differ from k_mlp_mfma's in the last bits (not from
+// each other between launches or tile positions: a leaf's evaluation is a function of the leaf alone).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ inline void split8(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)x[j];
+        const float r1 = x[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[j] = h;
+        mid[j] = m;
+        lo[j] = (__bf16)r2;
+    }
+}
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_mlp_bf16(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                       uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                       ar::EvalOut* out, float* logits) {
+    constexpr int MT = 2, L = 32 * MT;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4, n_ct = H >> 5;
+    float* act = smem;  // [L][ld], both hidden layers in turn
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    __shared__ float hl[L * 12];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int ct0 = 2 * wave;  // this wavefront's two column tiles: columns 64 wave .. 64 wave + 63
+    const bool has = ct0 < n_ct, two = ct0 + 1 < n_ct;
+    f32x16 c[MT][2];
+    const bf16x8* w1[3] = {(const bf16x8*)net.w1p[0], (const bf16x8*)net.w1p[1], (const bf16x8*)net.w1p[2]};
+    const bf16x8* w2[3] = {(const bf16x8*)net.w2p[0], (const bf16x8*)net.w2p[1], (const bf16x8*)net.w2p[2]};
+    // B fragments of one k16-step: [plane][column tile]
+    auto load_b = [&](const bf16x8* const* w, int k16, bf16x8 (&b)[3][2]) {
+        const size_t at = ((size_t)k16 * n_ct + ct0) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            b[p][0] = w[p][at];
+            b[p][1] = w[p][at + (two ? 64 : 0)];
+        }
+    };
+    auto mma6 = [&](const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8 (&b)[3][2], int t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0][j], c[t][j], 0, 0, 0);  // smallest terms first
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0][j], c[t][j], 0, 0, 0);
+        }
+    };
+    auto mma3 = [&](const bf16x8& ah, const bf16x8 (&b)[3][2], int t) {  // an operand that IS bf16 (one-hot inputs)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1][j], c[t][j], 0, 0, 0);
+            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0][j], c[t][j], 0, 0, 0);
+        }
+    };
+    auto store_relu = [&]() {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                act[(size_t)i * ld + 32 * ct0 + r] = fmaxf(c[t][0][v], 0.0f);
+                if (two) act[(size_t)i * ld + 32 * ct0 + 32 + r] = fmaxf(c[t][1][v], 0.0f);
+            }
+    };
+    if (has) {
+        // ---- first layer: x = [p1 one-hot | p2 one-hot | cheese mask | six scalars], accumulator = per-maze constant
+        int p1[MT], p2[MT];
+        unsigned long long ch[MT][NW];
+        float sc[MT][6];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const LeafFeat& f = feat[32 * t + r];
+            p1[t] = f.p1;
+            p2[t] = f.p2;
+            for (int s6 = 0; s6 < 6; ++s6) sc[t][s6] = f.sc[s6];
+            for (int w = 0; w < NW; ++w) ch[t][w] = cheese[32 * t + r][w];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + 32 * ct0 + r;
+                c[t][0][v] = cm[0];
+                c[t][1][v] = cm[two ? 32 : 0];
+            }
+        auto x_of = [&](int kk, int t) -> float {
+            if (kk < hw) return kk == p1[t] ? 1.0f : 0.0f;
+            if (kk < 2 * hw) return kk - hw == p2[t] ? 1.0f : 0.0f;
+            if (kk < 3 * hw) {
+                const int bit = kk - 2 * hw;
+                unsigned long long word = ch[t][0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) word = (bit >> 6) == w ? ch[t][w] : word;
+                return (word >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
+            }
+            const int s6 = kk - 3 * hw;
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
+            return v;
+        };
+        bf16x8 bw[3][2], bn[3][2];
+        load_b(w1, 0, bw);
+        for (int k16 = 0; k16 < net.nk1; ++k16) {
+            if (k16 + 1 < net.nk1) load_b(w1, k16 + 1, bn);
+            const bool exact = 16 * k16 + 16 <= 3 * hw;  // block-uniform: no scalar input in this step
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = x_of(16 * k16 + 8 * h + j, t);
+                bf16x8 ah, am, al;
+                split8(x, ah, am, al);
+                if (exact) mma3(ah, bw, t);
+                else mma6(ah, am, al, bw, t);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bw[p][0] = bn[p][0];
+                bw[p][1] = bn[p][1];
+            }
+        }
+        store_relu();
+    }
+    __syncthreads();
+    if (has) {
+        // ---- second layer: result held in the accumulators until every wavefront is done reading `act`
+        const float b0 = net.b2[32 * ct0 + r], b1 = net.b2[32 * ct0 + (two ? 32 : 0) + r];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                c[t][0][v] = b0;
+                c[t][1][v] = b1;
+            }
+        bf16x8 bw[3][2], bn[3][2];
+        load_b(w2, 0, bw);
+        for (int k16 = 0; k16 < net.nk2; ++k16) {
+            if (k16 + 1 < net.nk2) load_b(w2, k16 + 1, bn);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float4* ap = (const float4*)(act + (size_t)(32 * t + r) * ld + 16 * k16 + 8 * h);
+                const float4 a0 = ap[0], a1 = ap[1];
+                const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                bf16x8 ah, am, al;
+                split8(x, ah, am, al);
+                mma6(ah, am, al, bw, t);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                bw[p][0] = bn[p][0];
+                bw[p][1] = bn[p][1];
+            }
+        }
+    }
+    __syncthreads();
+    if (has) store_relu();
+    __syncthreads();
+    heads_mfma16(net.wh, net.bh, 12, H, act, ld, hl, tid, 2 * MT);
+    __syncthreads();
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 5, o.p2);
+        o.v1 = softplusf(hh[10]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = hh[k];
+    }
+}
+
 __host__ __device__ inline bool mlp_all_mfma(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
 static const int MLP_MFMA_MT = 2;  // 64 leaves per block
 
@@ -989,6 +1196,16 @@ struct ArNet {
         for (Scratch& sc : scratch)
             if (sc.p) hipFree(sc.p);
     }
+    const void* upload_raw(const void* src, size_t bytes, bool& ok) {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes + 16) != hipSuccess) {
+            ok = false;
+            return nullptr;
+        }
+        allocs.push_back(d);
+        if (hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        return d;
+    }
     const float* upload(const std::vector<float>& v, bool& ok) {
         float* d = nullptr;
         if (hipMalloc((void**)&d, v.size() * 4 + 16) != hipSuccess) {
@@ -1000,6 +1217,43 @@ struct ArNet {
         return d;
     }
 };
+
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does)
+static inline uint16_t ar_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float ar_bf2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// rows [row0, row0 + K) of a transposed weight matrix wt[in][H] as three bf16 planes in the B-operand order of
+// v_mfma_f32_32x32x16_bf16: [k16][column tile][lane][8], lane l holds column 32 ct + (l & 31), k = 16 k16 + 8 (l >> 5) + j
+static void ar_split_planes(const std::vector<float>& wt, int row0, int K, int H, std::vector<uint16_t> (&planes)[3], int& nk) {
+    nk = (K + 15) / 16;
+    const int n_ct = H / 32;
+    for (auto& pl : planes) pl.assign((size_t)nk * n_ct * 64 * 8, 0);
+    for (int k16 = 0; k16 < nk; ++k16)
+        for (int ct = 0; ct < n_ct; ++ct)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * k16 + 8 * (lane >> 5) + j, col = 32 * ct + (lane & 31);
+                    if (k >= K) continue;
+                    const float x = wt[(size_t)(row0 + k) * H + col];
+                    const uint16_t hi = ar_f2bf(x);
+                    const float r1 = x - ar_bf2f(hi);
+                    const uint16_t mid = ar_f2bf(r1);
+                    const float r2 = r1 - ar_bf2f(mid);
+                    const size_t at = (((size_t)k16 * n_ct + ct) * 64 + lane) * 8 + j;
+                    planes[0][at] = hi;
+                    planes[1][at] = mid;
+                    planes[2][at] = ar_f2bf(r2);
+                }
+}
 
 static int net_build(const arnet::Blob& b, ArNet* net) {
     using namespace arnet;
@@ -1019,9 +1273,19 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         d.H = (int)out;
         d.w1t = net->upload(wt, ok);
         d.b1 = net->upload(bias, ok);
+        const bool split = mlp_all_mfma(d.H);
+        std::vector<uint16_t> planes[3];
+        if (split) {  // the non-maze rows of layer 1 (the maze rows are the per-maze constant)
+            ar_split_planes(wt, 4 * d.hw, 3 * d.hw + 6, d.H, planes, d.nk1);
+            for (int p3 = 0; p3 < 3; ++p3) d.w1p[p3] = net->upload_raw(planes[p3].data(), planes[p3].size() * 2, ok);
+        }
         if (!fold_linear(b, "trunk.4", "trunk.5", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
         d.w2t = net->upload(wt, ok);
         d.b2 = net->upload(bias, ok);
+        if (split) {
+            ar_split_planes(wt, 0, d.H, d.H, planes, d.nk2);
+            for (int p3 = 0; p3 < 3; ++p3) d.w2p[p3] = net->upload_raw(planes[p3].data(), planes[p3].size() * 2, ok);
+        }
         std::vector<float> wh((size_t)12 * d.H), bh(12);
         const char* heads[3] = {"policy_p1_head", "policy_p2_head", "value_head"};
         const int rows[3] = {5, 5, 2};
@@ -1192,8 +1456,12 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     if (n_max == 0) return AR_OK;
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
     static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
+    // the split-bf16 kernel is opt-in: measured no faster than the fp32-MFMA kernel on the bench workload (DESIGN.md
+    // section 7: the activation splits cost the VALU what the matrix pipe saves), and the fp32 kernel is bit-identical
+    // to the scalar loops
+    const bool mlp_bf16 = mlp_mfma && net->dev.w1p[0] != nullptr && getenv("AR_MLP_BF16") != nullptr;
     const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA");
-    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
+    const int tile = mlp_bf16 ? 64 : mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
                                                                         : sym_mfma ? 32 : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_CNN) {
@@ -1202,6 +1470,13 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
         hipLaunchKernelGGL(k_cnn<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max, boards,
                            board_stride, net->bound_pool, out, logits);
+    } else if (mlp_bf16) {
+        const size_t smem = (size_t)64 * (net->dev.H + 4) * 4;
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_mlp_bf16<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
+        hipLaunchKernelGGL(k_mlp_bf16<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
+                           board_stride, out, logits);
     } else if (mlp_mfma) {
         const size_t smem = (size_t)32 * mlp_mt * (net->dev.H + 4) * 4;
         const void* fn = mlp_mt == 1 ? (const void*)k_mlp_mfma<NW, 1> : (const void*)k_mlp_mfma<NW, 2>;
