@@ -1314,9 +1314,9 @@ struct ArenaHold {
 };
 
 // Which gather kernel the network path uses when AR_GATHER does not say: measured on the bench workload (DESIGN.md
-// section 7, profiles/r02_gather_ab.md) the eight-lanes-per-game kernel is 1.9x / 1.7x / 1.07x faster per launch at
-// 1024 / 8192 / 32768 resident games (its eight-fold wavefront count fills the SIMDs the lane-per-game kernel
-// leaves to one wavefront each) and 1.18x slower at 65536, where it executes 3.4x the instructions.
+// section 7, profiles/r02_gather_ab.md) the eight-lanes-per-game kernel is faster per launch at every size -- 1.9x /
+// 1.7x at 1024 / 8192 resident games, where its eight-fold wavefront count fills SIMDs the lane-per-game kernel leaves
+// to one wavefront or none, and still ahead at 65536 once the shared maze sits in LDS and three wavefronts share a SIMD.
 static bool default_gather8(uint32_t) { return true; }
 // its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
 static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
