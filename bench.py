@@ -281,7 +281,8 @@ def main() -> int:
     if has_net and stats.gather_secs > 0:
         launches = max(stats.gather_launches, 1)
         avg_launch_s = stats.gather_secs / launches
-        kernel = "k_gather"
+        # the library's default gather is the eight-lanes-per-game kernel; AR_GATHER=lane selects the other one
+        kernel = "k_gather" if os.environ.get("AR_GATHER", "") == "lane" else "k_gather8"
     else:  # SmartUniform: one fused step kernel, timed as a whole
         gather_bytes += (B_NODE_VISIT - B_SELECT_VISIT) * stats.backup_node_visits
         launches = max(stats.steps, 1)
@@ -290,7 +291,7 @@ def main() -> int:
     achieved = gather_bytes / launches / max(avg_launch_s, 1e-12) / 1e9
     step_bytes = (B_NODE_VISIT * (stats.gather_node_visits + stats.backup_node_visits) + B_NEW_NODE * stats.new_nodes
                   + (B_NN_LEAF * stats.total_nn_evals if has_net else 0))
-    traffic, traffic_source = committed_traffic("k_gather" if has_net else "k_step_uniform", args.evaluator, args.resident)
+    traffic, traffic_source = committed_traffic(kernel if has_net else "k_step_uniform", args.evaluator, args.resident)
     out = {
         "metric": "MCTS simulations/sec, self-play 7x7 PyRat at the tuned 1897-sim config",
         "value": tot["sims"] / elapsed,
