@@ -953,6 +953,24 @@ __global__ void k_cache_fill(const LeafReq<NW>* miss_queue, const uint32_t* miss
     }
 }
 
+// SmartUniformBackend (backend.rs:92-103) as an evaluator of the leaf queue: the split pipeline (k_gather8 -> this ->
+// k_backup16) then serves uniform-prior runs too; the values are what the fused k_step_uniform computes inline
+// (emit_proc, EVAL_UNIFORM).
+template <int NW>
+__global__ void k_uniform_eval(const LeafReq<NW>* queue, const uint32_t* n_ptr, const Slot<NW>* slots, const uint8_t* maze,
+                               EvalOut* ev_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const LeafReq<NW> r = queue[i];
+    const uint8_t* cost = maze + slots[r.slot].board.maze_off;
+    EvalOut o;
+    uniform_prior(eff_actions(cost, r.st.p1, r.st.m1), o.p1);
+    uniform_prior(eff_actions(cost, r.st.p2, r.st.m2), o.p2);
+    o.v1 = 0.0f;
+    o.v2 = 0.0f;
+    ev_out[i] = o;
+}
+
 // host-callback evaluator support: leaves out, results in (single-slot searches)
 template <int NW>
 __global__ void k_export_leaves(const Slot<NW>* slots, uint32_t slot, Bases B, State<NW>* out, uint32_t* n_out) {
@@ -1321,6 +1339,9 @@ static bool default_gather8(uint32_t) { return true; }
 // its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
 static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
 static bool default_hybrid(uint32_t) { return false; }
+// measured (BASELINE config 2: 5x5, 1000 sims, 4096 games: 71.1 M vs 41.5 M simulations/s through the split pipeline;
+// 7x7 / 1897 sims at 65536 games: 1180 M vs 1251 M): few games want k_gather8's wavefront count, many the fused kernel
+static bool default_uniform_queue(uint32_t resident_games) { return resident_games <= 16384u; }
 
 template <int NW>
 struct Engine {
@@ -1375,6 +1396,8 @@ struct Engine {
     uint32_t lanes = 64;  // games per wavefront in k_gather / k_backup
     uint32_t backup_lanes = 64;  // games per wavefront in the network path's k_backup (AR_BACKUP_LANES)
     bool backup16 = false;       // network path: the sixteen-lanes-per-game backup (k_backup16 + k_finish) instead of k_backup
+    bool uniform_queue = false;  // SmartUniform through the split pipeline (leaf queue + k_uniform_eval) instead of k_step_uniform
+    bool use_queue() const { return net != nullptr || uniform_queue; }
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
@@ -1703,7 +1726,7 @@ struct Engine {
             gather_ev_used += 2;
         }
         const uint32_t n_max = (uint32_t)((size_t)n * cfg.batch_size);
-        if (cache_entries) {
+        if (cache_entries && net != nullptr) {
             LeafReq<NW>* mq = miss_queue.p + (size_t)g.first * cfg.batch_size;
             uint32_t* mm = miss_map.p + (size_t)g.first * cfg.batch_size;
             EvalOut* em = ev_miss.p + (size_t)g.first * cfg.batch_size;
@@ -1714,6 +1737,8 @@ struct Engine {
             if (int rc = net_forward_queue<NW>(net, mq, mc, n_max, slots.p, maze.p, em, g.stream)) return rc;
             hipLaunchKernelGGL(k_cache_fill<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, mq, mm, mc, em, slots.p,
                                cache_table.p, cache_entries - 1, ev, per_slot_maze ? 1u : 0u);
+        } else if (net == nullptr) {
+            hipLaunchKernelGGL(k_uniform_eval<NW>, dim3((n_max + 255) / 256), dim3(256), 0, g.stream, q, qc, slots.p, maze.p, ev);
         } else if (int rc = net_forward_queue<NW>(net, q, qc, n_max, slots.p, maze.p, ev, g.stream)) {
             return rc;
         }
@@ -1763,7 +1788,7 @@ struct Engine {
     int run_steps(int n_launch, int iters) {
         if (!timed) HIP_TRY(hipEventRecord(ev0, stream));  // several calls between two scans are timed as one interval
         for (int k = 0; k < n_launch; ++k) {
-            if (net == nullptr) {
+            if (!use_queue()) {
                 hipLaunchKernelGGL(k_step_uniform<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, cfg, bases(), zig.p,
                                    iters);
                 launch_advance();
@@ -1772,7 +1797,7 @@ struct Engine {
                 steps += (uint64_t)iters;
             }
         }
-        if (net != nullptr) {
+        if (use_queue()) {
             if (groups.empty())
                 if (int rc = make_groups(1)) return rc;
             const bool multi = groups.size() > 1;
@@ -2243,8 +2268,12 @@ struct SelfPlaySession : SessionBase {
             free_b += arena_cached_bytes(device);  // the block kept from the previous call is ours to reuse
             if (const char* e = getenv("AR_MEM_FRACTION"))  // several processes on one device (bench rehearsals): each
                 if (atof(e) > 0.0 && atof(e) <= 1.0) free_b = (size_t)((double)free_b * atof(e));  // takes its share
+            // SmartUniform runs: the fused step kernel, or the split pipeline of the network path with k_uniform_eval as
+            // its evaluator (AR_UNIFORM=fused | queue; results are identical)
+            eng.uniform_queue = net == nullptr && default_uniform_queue(S);
+            if (const char* e = getenv("AR_UNIFORM")) eng.uniform_queue = net == nullptr && std::string(e) == "queue";
             const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
-                                    Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr);
+                                    Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr || eng.uniform_queue);
             const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
             if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
             if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
@@ -2276,7 +2305,7 @@ struct SelfPlaySession : SessionBase {
         {
             // generated mazes: one pool entry per slot (filled when a game starts there); open: the one shared maze
             const std::vector<uint8_t> pool_init = gen_maze ? std::vector<uint8_t>((size_t)S * hw * 4, (uint8_t)0) : cost;
-            if (int rc = eng.setup(device, S, cfg, p.max_turns, pool_init, arena_nodes, net != nullptr, pool_bytes)) return rc;
+            if (int rc = eng.setup(device, S, cfg, p.max_turns, pool_init, arena_nodes, net != nullptr || eng.uniform_queue, pool_bytes)) return rc;
         }
         tm[0] = since(tp);
         // rounds per gather launch (dev_search.h gather_machine_limited); AR_GATHER_ROUNDS overrides, 0 = no limit
@@ -2575,11 +2604,13 @@ int search_impl(const ArGameSpec* games, uint32_t n, const SearchCfg& cfg, const
     }
     Engine<NW> eng;
     eng.net = predict_fn ? nullptr : net;
+    eng.uniform_queue = !predict_fn && net == nullptr && default_uniform_queue(n);
+    if (const char* e = getenv("AR_UNIFORM")) eng.uniform_queue = !predict_fn && net == nullptr && std::string(e) == "queue";
     if (eng.net != nullptr)
         for (uint32_t i = 0; i < n; ++i)
             if (games[i].width != net->dev.width || games[i].height != net->dev.height)
                 return fail(AR_E_INVALID, "game size does not match the network's board size");
-    if (int rc = eng.setup(device, n, cfg, max_turns, mazes, 0, eng.net != nullptr)) return rc;
+    if (int rc = eng.setup(device, n, cfg, max_turns, mazes, 0, eng.use_queue())) return rc;
     std::vector<GameInit<NW>> inits(n);
     std::random_device rd;
     for (uint32_t i = 0; i < n; ++i) {

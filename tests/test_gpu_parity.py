@@ -149,6 +149,27 @@ def test_selfplay_records_bit_exact(w, h, cheese, turns, sims, batch, kw, n_game
     assert stats.gather_node_visits == tot["gv"] and stats.backup_node_visits == tot["bv"]
 
 
+def test_uniform_runs_are_the_same_through_the_split_pipeline(monkeypatch):
+    """SmartUniform games through k_gather8 -> k_uniform_eval -> k_backup16 (AR_UNIFORM=queue) and through the fused
+    k_step_uniform: identical records, and both equal the oracle's."""
+    from alpharat_amd.sampling import rust_self_play
+
+    def run(mode):
+        monkeypatch.setenv("AR_UNIFORM", mode)
+        games = {}
+        rust_self_play(width=5, height=5, cheese_count=5, max_turns=30, num_games=40, simulations=300, batch_size=16,
+                       output_dir=None, seed=0, concurrent_games=24, noise_epsilon=0.25,
+                       on_game=lambda g: games.__setitem__(g["game_index"], g), **TUNED)
+        return games
+
+    a, b = run("fused"), run("queue")
+    cfg = O.make_config(noise_epsilon=0.25, **TUNED)
+    for i in sorted(a):
+        want = O.play_game(O.Game(5, 5, 30).random_cheese(5, True, i), cfg, 300, 16, 0xA1FA0000 + i)
+        _check_game(a[i], want)
+        _check_game(b[i], want)
+
+
 def test_selfplay_full_size_properties():
     """BASELINE config 2 at full width (4096 concurrent 5x5 games, 1000 sims): size-independent
     properties instead of an oracle replay -- conservation of cheese, policy normalisation, sampled

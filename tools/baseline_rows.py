@@ -41,7 +41,7 @@ def c2():
     dt = time.perf_counter() - t0
     nv = st.gather_node_visits + st.backup_node_visits
     bytes_ = 300 * nv + 304 * st.new_nodes
-    return {"row": "C2", "where": "1 MI355X, k_step_uniform + k_advance", "games": st.total_games, "wall_s": dt,
+    return {"row": "C2", "where": "1 MI355X, k_gather8 + k_uniform_eval + k_backup16 + k_advance (AR_UNIFORM=fused: k_step_uniform)", "games": st.total_games, "wall_s": dt,
             "games_per_sec": st.total_games / dt, "simulations_per_sec": st.total_simulations / dt,
             "descents_per_sec": (st.total_nn_evals + st.total_terminals) / dt, "node_visits_per_sec": nv / dt,
             "device_secs": st.device_secs, "algorithmic_GBps_in_kernels": bytes_ / max(st.device_secs, 1e-9) / 1e9,
