@@ -324,6 +324,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     m.max_depth = B.L.max_depth;
     const Board board = S.board;
     __shared__ OctShared<NW> shared[8];
+    __shared__ OutcomeTable otab;
+    outcome_table_fill(otab);
     OctShared<NW>& sh = shared[threadIdx.x >> 3];
     Oct<NW> o;
     o.done = true;
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
     for (uint32_t guard = 0; guard < (1u << 22); ++guard) {  // (every game's gather ends; the bound is a fuse)
         if (!__any(!o.done)) break;
-        gather8_round(o, sh, board, m, cfg, ol);
+        gather8_round(o, sh, otab, board, m, cfg, ol);
     }
     __syncthreads();
     if (!run) return;

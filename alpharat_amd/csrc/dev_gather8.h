@@ -48,6 +48,39 @@ struct alignas(16) LevelO {
     State<NW> saved;
 };
 
+// node.rs:251-283 compute_outcomes for the 17 effective-action maps a cell can have (each of the four moves open or
+// blocked; or stuck in mud: everything is STAY), tabulated once per block: a new node's two maps are two LDS reads
+// instead of two runs of pack_outcomes (~50 instructions each, executed by the whole wavefront whenever ANY of its
+// eight games creates a node, i.e. in most rounds)
+struct OutcomeTable {
+    uint32_t omap[17];
+    uint32_t n[17];
+};
+__device__ inline void outcome_table_fill(OutcomeTable& t) {  // lanes 0..16 of the block
+    const uint32_t k = threadIdx.x;
+    if (k < 17) {
+        uint32_t eff = 4u << 12;
+        if (k == 16) {
+            eff = 4u | (4u << 3) | (4u << 6) | (4u << 9) | (4u << 12);
+        } else {
+            eff |= (k & 1u) ? 4u : 0u;            // bit d set: direction d is blocked -> STAY
+            eff |= ((k & 2u) ? 4u : 1u) << 3;
+            eff |= ((k & 4u) ? 4u : 2u) << 6;
+            eff |= ((k & 8u) ? 4u : 3u) << 9;
+        }
+        uint32_t om, nn;
+        pack_outcomes(eff, om, nn);
+        t.omap[k] = om;
+        t.n[k] = nn;
+    }
+}
+// the table key of a player at `cell` with mud timer `mud` (same case split as eff_actions, dev_engine.h)
+__device__ inline uint32_t outcome_key(const uint8_t* cost, uint8_t cell, uint8_t mud) {
+    if (mud > 0) return 16u;
+    const uint32_t c = cell_costs(cost, cell);
+    return ((c & 0xffu) ? 0u : 1u) | (((c >> 8) & 0xffu) ? 0u : 2u) | (((c >> 16) & 0xffu) ? 0u : 4u) | (((c >> 24) & 0xffu) ? 0u : 8u);
+}
+
 // what an octet touches rarely lives in LDS (coherent inside the wavefront, no registers): the game's random
 // stream -- only tie breaks draw from it, search.rs:511-532 -- and the root position, read once per pick
 template <int NW>
@@ -155,8 +188,8 @@ __device__ inline uint32_t vtc_of(float util, float num, uint32_t ns, float seco
 
 // One round of an octet's gather: the same decisions in the same order as gather_round (dev_search.h).
 template <int NW>
-__device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Board& board, const OctMem<NW>& m,
-                                     const SearchCfg& cfg, uint32_t ol) {
+__device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const OutcomeTable& otab, const Board& board,
+                                     const OctMem<NW>& m, const SearchCfg& cfg, uint32_t ol) {
     if (o.done) return;
     o.rounds += 1;
     if (o.alloc_left == 0) {
@@ -233,12 +266,10 @@ __device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Board&
                             g1.z = __float_as_uint(r2);
                             g1.w = o.node;
                         } else if (ol == 4) {  // h2: outcome maps, counts, terminal flag
-                            uint32_t nn1, nn2, om0, om1;
-                            pack_outcomes(eff_actions(m.cost(), pos.p1, pos.m1), om0, nn1);
-                            pack_outcomes(eff_actions(m.cost(), pos.p2, pos.m2), om1, nn2);
-                            g1.x = om0;
-                            g1.y = om1;
-                            g1.z = nn1 | (nn2 << 8) | (o1 << 16) | (o2 << 24);
+                            const uint32_t k1 = outcome_key(m.cost(), pos.p1, pos.m1), k2 = outcome_key(m.cost(), pos.p2, pos.m2);
+                            g1.x = otab.omap[k1];
+                            g1.y = otab.omap[k2];
+                            g1.z = otab.n[k1] | (otab.n[k2] << 8) | (o1 << 16) | (o2 << 24);
                             g1.w = over ? 1u : 0u;
                         }
                         uint4* S = (uint4*)&m.stats[nid];
