@@ -151,6 +151,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # one hardware queue per stream of the step pipeline (see alpharat_hip.hip "hardware queues"): effective when the
+    # HIP runtime has not been initialised in this process yet
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

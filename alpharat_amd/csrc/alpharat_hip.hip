@@ -35,6 +35,21 @@
 using namespace ar;
 
 // ------------------------------------------------------------------------------------------------
+// hardware queues
+// ------------------------------------------------------------------------------------------------
+// The step pipeline of a large run keeps five streams busy at once (two groups of games x {walk + evaluator, tree
+// reuse} + the engine's own). The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default:
+// streams that share a queue serialise, and the pipeline runs 1.1-1.7x slower than with one queue per stream
+// (measured). The variable is read when the runtime initialises, so it is set when this
+// library is loaded -- unless the host has chosen a value itself. A process that brought the runtime up earlier
+// (e.g. torch imported first) has to export it itself: bench.py does.
+__attribute__((constructor)) static void ar_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+static int hw_queues() {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    return e ? atoi(e) : 4;
+}
+
+// ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_error;
@@ -1660,7 +1675,11 @@ struct Engine {
         for (uint32_t g = 0; g < n; ++g) {
             groups[g].first = (uint32_t)((uint64_t)S * g / n);
             groups[g].end = (uint32_t)((uint64_t)S * (g + 1) / n);
-            if (n > 1) {
+            // group 0 runs on the engine's own stream: with two groups that makes four streams (two step streams, two
+            // tree-reuse side streams), which is what the runtime maps to hardware queues by default (GPU_MAX_HW_QUEUES
+            // = 4); a fifth stream shares a queue with another and the pipeline collapses (measured: 321 M against
+            // 565 M simulations/s)
+            if (g > 0) {
                 HIP_TRY(hipStreamCreateWithFlags(&groups[g].stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].done, hipEventDisableTiming));
             } else {
@@ -1686,7 +1705,7 @@ struct Engine {
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
-        const bool timed_launch = gi == 0;
+        const bool timed_launch = true;  // every group's gather launch is timed on its own stream
         if (timed_launch) {
             while (gather_ev.size() < gather_ev_used + 2) {
                 hipEvent_t e = nullptr;
@@ -1802,17 +1821,16 @@ struct Engine {
         if (use_queue()) {
             if (groups.empty())
                 if (int rc = make_groups(1)) return rc;
-            const bool multi = groups.size() > 1;
             HIP_TRY(hipEventRecord(ev_order, stream));
             for (const Group& g : groups) {
-                if (multi) HIP_TRY(hipStreamWaitEvent(g.stream, ev_order, 0));
+                if (g.stream != stream) HIP_TRY(hipStreamWaitEvent(g.stream, ev_order, 0));
                 if (g.adv_stream) HIP_TRY(hipStreamWaitEvent(g.adv_stream, ev_order, 0));
             }
             for (int k = 0; k < n_launch * iters; ++k)
                 for (Group& g : groups)
                     if (int rc = group_step(g)) return rc;
             for (const Group& g : groups) {
-                if (multi) {
+                if (g.stream != stream) {
                     HIP_TRY(hipEventRecord(g.done, g.stream));
                     HIP_TRY(hipStreamWaitEvent(stream, g.done, 0));
                 }
@@ -2315,7 +2333,9 @@ struct SelfPlaySession : SessionBase {
         if (const char* e = getenv("AR_GATHER_ROUNDS")) eng.gather_rounds = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;
         {
             // groups of games pipelined against each other (Engine::group_step); AR_GROUPS overrides
-            uint32_t ng = 1;  // measured: more groups do not pay
+            // two groups from 8192 games up (one group's evaluator runs beside the other group's tree walks: +6..18 %,
+            // DESIGN.md section 7) -- when every stream can have a hardware queue of its own
+            uint32_t ng = (S >= 8192u && hw_queues() >= 8) ? 2u : 1u;
             if (const char* e = getenv("AR_GROUPS"))
                 if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
             if (eng.cache_entries) ng = 1;  // one probe/fill pair in flight at a time: a reader never overlaps an eviction

@@ -36,6 +36,9 @@ import time
 from pathlib import Path
 
 T_START = time.perf_counter()
+# one hardware queue per stream of the sampler's step pipeline; must be in the environment before anything (torch in
+# multi-rank runs) initialises the HIP runtime
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
@@ -325,6 +328,11 @@ def main() -> int:
             # exactly these kernel sources and this workload (counters cannot be read inside this process)
             "traffic": traffic, "traffic_source": traffic_source, "kernel_source_hash": kernel_source_hash(),
             "kernel": kernel, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+            # from 8192 resident games up the games run as two groups pipelined against each other (one group's
+            # evaluator beside the other's tree walks): a launch then covers half the games, overlapped with other
+            # kernels. The same kernel launched over all 65536 games at once (AR_GROUPS=1): 2.65 ms, frac 0.050, at
+            # 531 M simulations/s (profiles/r02_bench_1group.json) -- the pipelining buys throughput, not roofline.
+            "launches_per_batch_step": launches / max(stats.steps, 1),
             "algorithmic_bytes_per_launch": gather_bytes / launches,
             # the whole step (gather + evaluator + backup, tree reuse overlapped) for reference
             "step": {"batch_steps": stats.steps, "device_secs": stats.device_secs,
