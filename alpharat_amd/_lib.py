@@ -11,7 +11,7 @@ from pathlib import Path
 import os
 
 PKG = Path(__file__).resolve().parent
-# AR_LIB: another build of the same library (A/B measurements of two builds, tools/ab.py); never a different backend
+# AR_LIB: another build of the same library (A/B measurements of two builds); never a different backend
 LIB_PATH = Path(os.environ["AR_LIB"]) if os.environ.get("AR_LIB") else PKG / "libalpharat_hip.so"
 
 AR_OK, AR_E_INVALID, AR_E_BACKEND, AR_E_IO, AR_E_DEVICE, AR_E_NOMEM = 0, -1, -2, -3, -4, -5
