@@ -170,6 +170,8 @@ def main() -> int:
     ap.add_argument("--evaluator", choices=sorted(WORKLOADS), default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--no-full-launch", action="store_true",
+                    help="skip the extra leg that times the gather kernel launched over all resident games at once")
     ap.add_argument("--deadline", type=float, default=480.0,
                     help="seconds after process start at which the timed loop stops early and reports the steps done")
     args = ap.parse_args()
@@ -341,6 +343,35 @@ def main() -> int:
         },
         "timing": {"session_open_s": t_open, "timed_s": elapsed},
     }
+    # Extra leg (N=1, network evaluators): the same workload with the games as ONE group, i.e. the gather kernel launched
+    # over all resident games at once instead of two half-size launches pipelined against the evaluator. It is the
+    # kernel's best per-launch figure; the timed configuration above trades it for throughput.
+    if has_net and world == 1 and not args.no_full_launch and "AR_GROUPS" not in os.environ and \
+            (time.perf_counter() - T_START) < args.deadline - 120.0:
+        os.environ["AR_GROUPS"] = "1"
+        try:
+            with SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
+                                 weights_path=weights, seed=0, first_game_index=1 << 27, concurrent_games=args.resident,
+                                 device_index=local_rank, **search) as s1:
+                for _ in range(4):
+                    s1.step(args.batch_steps)
+                tf = time.perf_counter()
+                w1 = s1.step(args.batch_steps)
+                w1 = _sum_windows(w1, s1.step(args.batch_steps))
+                dt1 = time.perf_counter() - tf
+            b1 = (B_SELECT_VISIT * w1.gather_node_visits + B_NEW_NODE * w1.new_nodes + B_LEAF_REQ * w1.total_nn_evals)
+            l1 = max(w1.gather_launches, 1)
+            a1 = b1 / l1 / max(w1.gather_secs / l1, 1e-12) / 1e9
+            out["roofline"]["full_launch"] = {
+                "what": "same workload, AR_GROUPS=1: one gather launch over all resident games per batch step (2 timed steps "
+                        "after 4 warm-up steps of a fresh session)",
+                "achieved": a1, "frac": a1 / HBM_PEAK_GBS, "avg_launch_ms": w1.gather_secs / l1 * 1e3,
+                "algorithmic_bytes_per_launch": b1 / l1, "simulations_per_sec": w1.total_simulations / dt1,
+                "avg_step_ms": w1.device_secs / max(w1.steps, 1) * 1e3}
+        except Exception as e:  # noqa: BLE001 -- the extra leg never costs the headline line
+            out["roofline"]["full_launch"] = {"error": str(e)}
+        finally:
+            os.environ.pop("AR_GROUPS", None)
     if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N=1 only
         left = args.deadline + 60.0 - (time.perf_counter() - T_START)
         if left > args.cpu_secs + 15.0:
