@@ -1139,6 +1139,164 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma(NetDev net, const a
             }
     }
 }
+// ---- the same with BOTH players of a leaf in one pass ------------------------------------------------------------
+// k_symmetric_mfma streams the trunk's weights (the bulk: (2H + H) x H) through once per player per 32-leaf block,
+// ~49 KB of L2 reads per leaf. Here a block's rows are (player, leaf) pairs -- 64 rows for 32 leaves -- so the player
+// encoder, both trunk layers and the heads run once over two row tiles and the trunk weights are read once per block:
+// half the L2 traffic, four independent accumulator chains per wavefront. Per output the k-ordered chain is unchanged
+// (same bits as k_symmetric_mfma and the FMA loops). LDS: shared encoding [32][ld] + one [64][ld] buffer that holds
+// the player encodings, then trunk 1, then h (100 KB at H = 256: one block per CU).
+template <int NW>
+__global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                              uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                              ar::EvalOut* out, float* logits) {
+    constexpr int L = 32;
+    extern __shared__ float smem[];
+    const int H = net.H, hw = net.hw, ld = H + 4;
+    float* bufA = smem;                    // shared encoding [L][ld]
+    float* bufB = smem + (size_t)L * ld;   // [2 L][ld]: row = player * L + leaf
+    __shared__ LeafFeat feat[L];
+    __shared__ unsigned long long cheese[L][4];
+    __shared__ float hl[L * 12];
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& r = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
+        leaf_features<NW>(r.st, b, hw, feat[tid]);
+        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
+    const int c1 = two ? 32 : 0;
+    const LeafFeat f = feat[r];  // this lane's leaf (row r of either row tile)
+    unsigned long long ch[NW];
+    for (int w = 0; w < NW; ++w) ch[w] = cheese[r][w];
+    f32x16 c[2][2];  // [row tile = player][column tile]
+    auto store_relu2 = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                bufB[(size_t)i * ld + n0 + r] = fmaxf(c[t][0][v], 0.0f);
+                if (two) bufB[(size_t)i * ld + n0 + 32 + r] = fmaxf(c[t][1][v], 0.0f);
+            }
+    };
+    auto init_bias2 = [&](const float* bias) {
+        const float b0 = bias[n0 + r], b1 = bias[n0 + c1 + r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                c[t][0][v] = b0;
+                c[t][1][v] = b1;
+            }
+    };
+    if (has) {
+        // ---- shared encoder (one row tile: the 32 leaves) -> A
+        f32x16 cs[1][2];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+            const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + n0 + r;
+            cs[0][0][v] = cm[0];
+            cs[0][1][v] = cm[c1];
+        }
+        auto x_sh = [&](int k, int) -> float {
+            const int kk = k + h;
+            if (kk < hw) {
+                unsigned long long word = ch[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) word = (kk >> 6) == w ? ch[w] : word;
+                return (word >> (kk & 63)) & 1ULL ? 1.0f : 0.0f;
+            }
+            return kk == hw ? f.sc[1] : 0.0f;
+        };
+        mfma_pass<1, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, hw + 1, H, h, x_sh, cs);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
+            bufA[(size_t)i * ld + n0 + r] = fmaxf(cs[0][0][v], 0.0f);
+            if (two) bufA[(size_t)i * ld + n0 + 32 + r] = fmaxf(cs[0][1][v], 0.0f);
+        }
+        // ---- player encoder, both players (row tile t = player) -> B
+        init_bias2(net.bp);
+        auto x_pe = [&](int k, int t) -> float {
+            const int kk = k + h;
+            const int pos = t == 0 ? f.p1 : f.p2;
+            if (kk < hw) return kk == pos ? 1.0f : 0.0f;
+            return kk == hw ? f.sc[2 + t] : kk == hw + 1 ? f.sc[4 + t] : 0.0f;
+        };
+        mfma_pass<2, 8>(net.wpt + (size_t)h * H + n0 + r, two, hw + 2, H, h, x_pe, c);
+        store_relu2();
+    }
+    __syncthreads();
+    if (has) {
+        // ---- trunk 1: k over the shared encoding (row r of A for both players), then over the player encodings
+        init_bias2(net.b2);
+        const float* ap = bufA + (size_t)r * ld + h;
+        auto a_sh = [&](int k, int) -> float { return ap[k]; };
+        mfma_pass<2, 8>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_sh, c);
+        const float* bp = bufB + (size_t)r * ld + h;
+        auto a_pe = [&](int k, int t) -> float { return bp[(size_t)(32 * t) * ld + k]; };
+        mfma_pass<2, 8>(net.w2t + (size_t)(H + h) * H + n0 + r, two, H, H, h, a_pe, c);
+    }
+    __syncthreads();
+    if (has) store_relu2();
+    __syncthreads();
+    if (has) {
+        // ---- trunk 2
+        init_bias2(net.b3);
+        const float* bp = bufB + (size_t)r * ld + h;
+        auto a_t1 = [&](int k, int t) -> float { return bp[(size_t)(32 * t) * ld + k]; };
+        mfma_pass<2, 8>(net.w3t + (size_t)h * H + n0 + r, two, H, H, h, a_t1, c);
+    }
+    __syncthreads();
+    if (has) store_relu2();  // h: rows 0..31 player 1, rows 32..63 player 2
+    __syncthreads();
+    // ---- heads on cat(h_p, h_1 + h_2): wavefront = (player, 16-leaf half); rows: policy 5, value 1
+    {
+        const int pl = wave >> 1, half = wave & 1, rr = lane & 15, qq = lane >> 4;
+        const bool col = rr < 6;
+        const float* ha = bufB + (size_t)(half * 16 + rr) * ld + qq;
+        const float* hb = bufB + (size_t)(32 + half * 16 + rr) * ld + qq;
+        const float* hp = pl == 0 ? ha : hb;
+        const float* wp = net.wh + (size_t)(col ? rr : 0) * (2 * H) + qq;
+        const float b = col ? net.bh[rr] : 0.0f;
+        f32x4 acc = {b, b, b, b};
+#pragma unroll 8
+        for (int k = 0; k < H; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[k], col ? wp[k] : 0.0f, acc, 0, 0, 0);
+#pragma unroll 8
+        for (int k = 0; k < H; k += 4)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[k] + hb[k], col ? wp[H + k] : 0.0f, acc, 0, 0, 0);
+        if (col)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) hl[(half * 16 + 4 * qq + v) * 12 + pl * 6 + rr] = acc[v];
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 6, o.p2);
+        o.v1 = softplusf(hh[5]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 5; ++k) {
+                logits[(size_t)(base + tid) * 10 + k] = hh[k];
+                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
+            }
+    }
+}
+
 __host__ __device__ inline bool symmetric_mfma_ok(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
 
 // flat observation (flat_encoder.rs:52-125), one block per position
@@ -1494,6 +1652,13 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
                 hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
         hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
+                           board_stride, out, logits);
+    } else if (sym_mfma && getenv("AR_SYM_PER_PLAYER") == nullptr) {
+        const size_t smem = (size_t)3 * 32 * (net->dev.H + 4) * 4;
+        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric_mfma2<NW>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
+        hipLaunchKernelGGL(k_symmetric_mfma2<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
     } else if (sym_mfma) {
         const size_t smem = (size_t)2 * 32 * (net->dev.H + 4) * 4;
