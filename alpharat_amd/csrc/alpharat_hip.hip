@@ -29,6 +29,7 @@
 #include "npz_writer.h"
 #include "slot_layout.h"
 #include "dev_gather8.h"
+#include "dev_gather2.h"
 #include "dev_backup16.h"
 #include "zig_norm_tables.inc"
 
@@ -430,6 +431,230 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
         }
     }
     if (ol == 0) {
+        if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
+        S.status = tag_status(status, phase);
+    }
+}
+
+// The same gather with two lanes per game (dev_gather2.h): a wavefront holds 32 games, a pair of lanes -- one per
+// player -- walks one tree. Launched with ceil(n / 32) blocks of 64 threads, two wavefronts per SIMD (256 VGPRs).
+// All wavefronts of a launch are resident at once, so the launch lasts as long as its longest walk: after `max_rounds`
+// rounds the games still walking are parked (PairParked) and continue in the next launch.
+// (LIMIT: the instance with the park / resume code; the plain one has no spills)
+template <int NW, bool LIMIT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gather2(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
+                                                uint32_t phase, uint32_t accept_ready, uint32_t max_rounds) {
+    static_assert(sizeof(PairParked<NW>) <= PAIR_PARK_BYTES + sizeof(State<NW>), "slot_layout.h reserves the parked gather");
+#if defined(AR_STATS)
+    const unsigned long long clk_entry = wall_clock64();
+#endif
+    const uint32_t p = threadIdx.x & 1u;
+    const uint32_t i = first + blockIdx.x * 32u + (threadIdx.x >> 1);
+    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
+    bool run = i < n_slots;
+    if (run) {
+        const uint32_t st = slots[i].status;
+        run = st == SLOT_ACTIVE || st == accept_ready;
+    }
+    const uint32_t ii = i < n_slots ? i : first;  // idle pairs read a valid slot and store nothing
+    Slot<NW>& S = slots[ii];
+    OctMem<NW> m;
+    m.stats = (NodeStats*)(B.arena + S.stats_off);
+    m.kids = (NodeKids*)(B.arena + S.kids_off);
+    m.scratch = B.scratch;
+    m.maze = B.maze;
+    if (B.maze_stage) {
+        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
+        m.maze = (const uint8_t*)lds_maze;  // (the barrier below, in front of the rounds, orders these writes)
+    }
+    m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
+    m.maze_off = S.board.maze_off;
+    m.proc_off = (uint32_t)B.L.proc_off;
+    m.coll_off = (uint32_t)B.L.coll_off;
+    m.levels_off = (uint32_t)B.L.levels_off;
+    m.leaf_off = (uint32_t)B.L.leaf_off;
+    m.coll_cap = B.L.coll_cap;
+    m.max_depth = B.L.max_depth;
+    PairParked<NW>& park = *(PairParked<NW>*)(B.scratch + ((size_t)ii * B.L.total + B.L.glane_off));
+    const Board board = S.board;
+    __shared__ PairShared<NW> shared[32];
+    __shared__ OutcomeTable otab;
+    outcome_table_fill(otab);
+    PairShared<NW>& sh = shared[threadIdx.x >> 1];
+    const uint32_t q0 = p ? 4u : 0u, qn = p ? 3u : 4u;  // this lane's quarters of a 25-entry table
+    Pair<NW> o;
+    o.done = true;
+    o.alloc_left = 0;
+    o.error = 0;
+    o.d_new = o.d_visits = 0;
+    o.rounds = 0;
+    o.batch_active = S.batch_active;
+    bool stalled = false;
+    // a batch that was already gathered and still waits for its backup is left alone
+    const bool walk = run && o.batch_active == 0;
+    const bool resume = LIMIT && walk && S.gather_pending != 0;
+    const bool begin = walk && !resume;
+    if (walk) {
+        o.hi = S.hi;
+        o.cap = S.cap;
+        o.root = S.root;
+        o.node_count = S.node_count;
+        if (p == 0) pair_rng_store(sh.rng, S.rng);
+        sh.root_st = S.st;  // (both lanes store the same values and read back their own)
+    }
+    if (begin) {
+        // gather_begin (dev_search.h)
+        const uint32_t remaining = S.remaining;
+        o.batch = remaining < cfg.batch_size ? remaining : cfg.batch_size;
+        if (o.hi + o.batch > o.cap) {
+            stalled = true;
+        } else {
+            o.left = (long long)(int32_t)collisions_left(o.node_count, cfg);
+            o.n_proc = o.n_coll = o.b_nn = o.b_term = o.b_coll = 0;
+            o.depth = 0;
+            o.node = 0;
+            o.mask = 0;
+            o.omap0 = o.omap1 = 0;
+            o.pick_mv = 0;
+            o.have_pick = false;
+            o.work = S.st;
+            o.h.n = 0;
+            o.h.forced = 0;
+            for (int k = 0; k < 5; ++k) {
+                o.h.score[k] = o.h.util[k] = o.h.num[k] = 0.0f;
+                o.h.ns[k] = o.h.add[k] = o.h.nif0[k] = 0;
+            }
+            o.done = false;
+        }
+    }
+    if constexpr (LIMIT) if (resume) {
+        o.batch = park.batch;
+        o.depth = park.depth;
+        o.node = park.node;
+        o.mask = park.mask;
+        o.omap0 = park.omap0;
+        o.omap1 = park.omap1;
+        o.pick_mv = park.pick_mv;
+        o.have_pick = park.have_pick != 0;
+        o.alloc_left = park.alloc_left;
+        o.n_proc = park.n_proc;
+        o.n_coll = park.n_coll;
+        o.b_nn = park.b_nn;
+        o.b_term = park.b_term;
+        o.b_coll = park.b_coll;
+        o.error = park.error;
+        o.left = park.left;
+        o.work = park.work;
+        half_copy(o.h, park.h[p]);
+        volatile u32x4* kid4 = (volatile u32x4*)sh.kid;
+        volatile u32x4* vtp4 = (volatile u32x4*)sh.vtp;
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (j < qn) {
+                kid4[q0 + j] = ((const u32x4*)park.kid)[q0 + j];
+                vtp4[q0 + j] = ((const u32x4*)park.vtp)[q0 + j];
+            }
+        }
+        o.done = false;
+    }
+    __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
+    const uint32_t fuse = LIMIT && max_rounds < (1u << 22) ? max_rounds : (1u << 22);
+#if defined(AR_STATS)
+    const unsigned long long clk_loop = wall_clock64();
+    uint32_t wave_rounds = 0;
+#endif
+    for (uint32_t r = 0; r < fuse; ++r) {  // (every game's gather ends; without a round limit the bound is a fuse)
+        if (!__any(!o.done)) break;
+        gather2_round(o, sh, otab, board, m, cfg, p);
+#if defined(AR_STATS)
+        wave_rounds += 1;
+#endif
+    }
+#if defined(AR_STATS)
+    if (threadIdx.x == 0) {  // [0] wavefronts, [1] their rounds, [2] loop ticks (100 MHz), [3] longest loop, [4] ticks from kernel entry to the loop
+        const unsigned long long dt = wall_clock64() - clk_loop;
+        atomicAdd(&ar::g_gather_clk[0], 1ULL);
+        atomicAdd(&ar::g_gather_clk[1], (unsigned long long)wave_rounds);
+        atomicAdd(&ar::g_gather_clk[2], dt);
+        atomicMax(&ar::g_gather_clk[3], dt);
+        atomicAdd(&ar::g_gather_clk[4], clk_loop - clk_entry);
+        atomicAdd(&ar::g_gather_clk[8 + (wave_rounds / 16 < 31 ? wave_rounds / 16 : 31)], 1ULL);   // wavefronts by rounds / 16
+        atomicAdd(&ar::g_gather_clk[40 + (wave_rounds / 16 < 31 ? wave_rounds / 16 : 31)], dt);    // their loop ticks
+    }
+#endif
+    __syncthreads();
+    if (!run) return;
+    const bool cut = walk && !stalled && !o.done;  // still walking at the limit
+    if (cut && (!LIMIT || max_rounds >= (1u << 22))) o.error = 8;  // the fuse blew
+    uint32_t status = SLOT_ACTIVE;
+    if (stalled) status = SLOT_STALL;
+    if (walk && !stalled) {
+        uint32_t base = 0;
+        const bool complete = o.done && o.batch_active != 0;
+        if (complete && queue != nullptr && o.b_nn > 0) {
+            if (p == 0) base = atomicAdd(queue_count, o.b_nn);
+            const uint32_t other = pair_swap(base);
+            base = p ? other : base;
+            for (uint32_t j = p; j < o.b_nn; j += 2) {
+                LeafReq<NW> r;
+                r.st = m.leaves()[j];
+                r.slot = i;
+                r.pad = 0;
+                queue[base + j] = r;
+            }
+        }
+        if constexpr (LIMIT) if (cut && o.error == 0) {
+            half_copy(park.h[p], o.h);
+            volatile u32x4* kid4 = (volatile u32x4*)sh.kid;
+            volatile u32x4* vtp4 = (volatile u32x4*)sh.vtp;
+            for (uint32_t j = 0; j < 4; ++j) {
+                if (j < qn) {
+                    ((u32x4*)park.kid)[q0 + j] = kid4[q0 + j];
+                    ((u32x4*)park.vtp)[q0 + j] = vtp4[q0 + j];
+                }
+            }
+        }
+        if (p == 0) {
+            S.hi = o.hi;
+            S.node_count = o.node_count;
+            S.new_nodes += o.d_new;
+            S.nv_gather += o.d_visits;
+            S.rng = pair_rng_load(sh.rng);
+            if (LIMIT && cut && o.error == 0) {
+                park.batch = o.batch;
+                park.depth = o.depth;
+                park.node = o.node;
+                park.mask = o.mask;
+                park.omap0 = o.omap0;
+                park.omap1 = o.omap1;
+                park.pick_mv = o.pick_mv;
+                park.have_pick = o.have_pick ? 1u : 0u;
+                park.alloc_left = o.alloc_left;
+                park.n_proc = o.n_proc;
+                park.n_coll = o.n_coll;
+                park.b_nn = o.b_nn;
+                park.b_term = o.b_term;
+                park.b_coll = o.b_coll;
+                park.error = o.error;
+                park.left = o.left;
+                park.work = o.work;
+                S.g_rounds = (resume ? S.g_rounds : 0u) + o.rounds;
+                S.gather_pending = 1;
+            } else {
+                S.n_proc = o.n_proc;
+                S.n_coll = o.n_coll;
+                S.b_nn = o.b_nn;
+                S.b_term = o.b_term;
+                S.b_coll = o.b_coll;
+                S.batch_active = o.batch_active;
+                S.eval_base = base;
+                S.g_rounds = (resume ? S.g_rounds : 0u) + o.rounds;
+                S.gather_pending = 0;
+                if (o.error) S.error = o.error;
+            }
+        }
+    }
+    if (p == 0) {
         if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
         S.status = tag_status(status, phase);
     }
@@ -1354,6 +1579,7 @@ struct ArenaHold {
 // to one wavefront or none, and still ahead at 65536 once the shared maze sits in LDS and three wavefronts share a SIMD.
 static bool default_gather8(uint32_t) { return true; }
 // its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
+static bool default_gather2(uint32_t) { return false; }
 static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
 static bool default_hybrid(uint32_t) { return false; }
 // measured (BASELINE config 2: 5x5, 1000 sims, 4096 games: 71.1 M vs 41.5 M simulations/s through the split pipeline;
@@ -1416,6 +1642,8 @@ struct Engine {
     bool uniform_queue = false;  // SmartUniform through the split pipeline (leaf queue + k_uniform_eval) instead of k_step_uniform
     bool use_queue() const { return net != nullptr || uniform_queue; }
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
+    bool gather2 = false; // network path: the two-lanes-per-game gather (k_gather2)
+    bool gather_mixed = false;  // odd groups of games walk with k_gather2, even groups with k_gather8 (AR_GATHER=mixed)
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
     bool hybrid = false;
@@ -1515,6 +1743,10 @@ struct Engine {
                 gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : std::string(e) == "octet2" ? 2 : gather8_wpe;
         hybrid = default_hybrid(S);
         if (const char* e = getenv("AR_GATHER")) hybrid = std::string(e) == "hybrid";
+        gather2 = default_gather2(S);
+        if (const char* e = getenv("AR_GATHER")) gather2 = std::string(e) == "pair";
+        if (const char* e = getenv("AR_GATHER")) gather_mixed = std::string(e) == "mixed";
+        if (gather_mixed) gather8 = true;
         if (const char* e = getenv("AR_HEAVY_FRAC"))
             if (atof(e) > 0.0 && atof(e) < 1.0) heavy_frac = (float)atof(e);
         if (hybrid && need_queue) {
@@ -1534,7 +1766,7 @@ struct Engine {
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
-        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = hybrid = false;  // k_gather8 addresses scratch with 32-bit offsets
+        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = gather2 = gather_mixed = hybrid = false;  // k_gather8 / k_gather2 address scratch with 32-bit offsets
         // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
         size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
         {
@@ -1730,7 +1962,16 @@ struct Engine {
                                (const uint32_t*)(part_ctrl.p + 1));
             HIP_TRY(hipStreamWaitEvent(g.stream, ev_heavy, 0));
             hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, g.stream, part_ctrl.p, heavy_frac, cap);
-        } else if (gather8 && gather8_wpe == 3)
+        } else if (gather2 || (gather_mixed && (gi & 1)))
+        {
+            if (gather_rounds != 0xFFFFFFFFu)
+                hipLaunchKernelGGL((k_gather2<NW, true>), dim3((n + 31) / 32), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                                   qc, g.first, phase, ready, gather_rounds);
+            else
+                hipLaunchKernelGGL((k_gather2<NW, false>), dim3((n + 31) / 32), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
+                                   qc, g.first, phase, ready, gather_rounds);
+        }
+        else if (gather8 && gather8_wpe == 3)
             hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
                                qc, g.first, phase, ready, no_list, no_list);
         else if (gather8 && gather8_wpe == 4)
@@ -2346,7 +2587,7 @@ struct SelfPlaySession : SessionBase {
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = eng.backup_lanes = (uint32_t)atoi(e);
         if (const char* e = getenv("AR_BACKUP_LANES"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.backup_lanes = (uint32_t)atoi(e);
-        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.hybrid = false;  // the round limit parks lane state: lane kernel only
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.hybrid = false;  // the round limit parks the walk: lane and pair kernels only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();

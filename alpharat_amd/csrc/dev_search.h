@@ -793,6 +793,7 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
 // parks its state in the slot's scratch and resumes at the next call; only complete batches go on to
 // the evaluator and the backup. Per-game results do not depend on where the cuts fall.
 enum { GATHER_STALLED = 0, GATHER_COMPLETE = 1, GATHER_PENDING = 2 };
+enum { PAIR_PARK_BYTES = 768 };  // slot_layout.h: room for dev_gather2.h's PairParked without its State
 template <int NW>
 AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode,
                                  uint32_t max_rounds) {

@@ -36,7 +36,10 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     L.pos_off = off;
     off = align_up(off + sizeof(PosRec<NW>) * (max_turns > 0 ? max_turns : 1), 64);
     L.glane_off = off;
-    off = align_up(off + sizeof(GatherLane<NW>), 256);
+    // (a parked gather: the lane kernel's GatherLane, or the pair kernel's PairParked -- dev_gather2.h: replicated walk
+    // state, two HalfAllocs, the current node's child table and allocated visits)
+    const size_t park_pair = PAIR_PARK_BYTES + sizeof(State<NW>);
+    off = align_up(off + (sizeof(GatherLane<NW>) > park_pair ? sizeof(GatherLane<NW>) : park_pair), 256);
     L.total = off;
     return L;
 }
