@@ -157,6 +157,31 @@ def cpu_baseline(blob: str | None, evaluator: str, max_secs: float) -> dict:
     }
 
 
+def full_launch_leg(evaluator: str, resident: int, batch_steps: int, device_index: int) -> dict:
+    """The extra leg (its own process, `--full-launch-child`): the same workload with the games as ONE group."""
+    from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession
+
+    search, sims, batch, _ = WORKLOADS[evaluator]
+    weights = weights_for(evaluator, 0)
+    with SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
+                         weights_path=weights, seed=0, first_game_index=1 << 27, concurrent_games=resident,
+                         device_index=device_index, **search) as s1:
+        for _ in range(4):
+            s1.step(batch_steps)
+        tf = time.perf_counter()
+        w1 = s1.step(batch_steps)
+        w1 = _sum_windows(w1, s1.step(batch_steps))
+        dt1 = time.perf_counter() - tf
+    b1 = (B_SELECT_VISIT * w1.gather_node_visits + B_NEW_NODE * w1.new_nodes + B_LEAF_REQ * w1.total_nn_evals)
+    l1 = max(w1.gather_launches, 1)
+    a1 = b1 / l1 / max(w1.gather_secs / l1, 1e-12) / 1e9
+    return {"what": "same workload, AR_GROUPS=1: one gather launch over all resident games per batch step (2 timed steps "
+                    "after 4 warm-up steps of a fresh session, in a child process)",
+            "achieved": a1, "frac": a1 / HBM_PEAK_GBS, "avg_launch_ms": w1.gather_secs / l1 * 1e3,
+            "algorithmic_bytes_per_launch": b1 / l1, "simulations_per_sec": w1.total_simulations / dt1,
+            "avg_step_ms": w1.device_secs / max(w1.steps, 1) * 1e3}
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +199,13 @@ def main() -> int:
                     help="skip the extra leg that times the gather kernel launched over all resident games at once")
     ap.add_argument("--deadline", type=float, default=480.0,
                     help="seconds after process start at which the timed loop stops early and reports the steps done")
+    ap.add_argument("--full-launch-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.full_launch_child:  # (the parent passes --evaluator / --resident / --batch-steps resolved)
+        print(json.dumps(full_launch_leg(args.evaluator, args.resident, args.batch_steps, int(os.environ.get("LOCAL_RANK", "0")))),
+              flush=True)
+        return 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -348,30 +379,22 @@ def main() -> int:
     # kernel's best per-launch figure; the timed configuration above trades it for throughput.
     if has_net and world == 1 and not args.no_full_launch and "AR_GROUPS" not in os.environ and \
             (time.perf_counter() - T_START) < args.deadline - 120.0:
-        os.environ["AR_GROUPS"] = "1"
+        # In a child process: the leg is an extra, and nothing that goes wrong in it -- not even a crash of the runtime --
+        # may cost the line above. (The session of the timed region is closed: its device memory is free.)
+        import subprocess
+
         try:
-            with SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
-                                 weights_path=weights, seed=0, first_game_index=1 << 27, concurrent_games=args.resident,
-                                 device_index=local_rank, **search) as s1:
-                for _ in range(4):
-                    s1.step(args.batch_steps)
-                tf = time.perf_counter()
-                w1 = s1.step(args.batch_steps)
-                w1 = _sum_windows(w1, s1.step(args.batch_steps))
-                dt1 = time.perf_counter() - tf
-            b1 = (B_SELECT_VISIT * w1.gather_node_visits + B_NEW_NODE * w1.new_nodes + B_LEAF_REQ * w1.total_nn_evals)
-            l1 = max(w1.gather_launches, 1)
-            a1 = b1 / l1 / max(w1.gather_secs / l1, 1e-12) / 1e9
-            out["roofline"]["full_launch"] = {
-                "what": "same workload, AR_GROUPS=1: one gather launch over all resident games per batch step (2 timed steps "
-                        "after 4 warm-up steps of a fresh session)",
-                "achieved": a1, "frac": a1 / HBM_PEAK_GBS, "avg_launch_ms": w1.gather_secs / l1 * 1e3,
-                "algorithmic_bytes_per_launch": b1 / l1, "simulations_per_sec": w1.total_simulations / dt1,
-                "avg_step_ms": w1.device_secs / max(w1.steps, 1) * 1e3}
+            left = max(args.deadline - (time.perf_counter() - T_START), 60.0)
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--full-launch-child", "--evaluator", args.evaluator,
+                                "--resident", str(args.resident), "--batch-steps", str(args.batch_steps)],
+                               env=dict(os.environ, AR_GROUPS="1"), capture_output=True, text=True, timeout=left)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                out["roofline"]["full_launch"] = json.loads(lines[-1])
+            else:
+                out["roofline"]["full_launch"] = {"error": f"child exited with {r.returncode}: {r.stderr.strip()[-300:]}"}
         except Exception as e:  # noqa: BLE001 -- the extra leg never costs the headline line
             out["roofline"]["full_launch"] = {"error": str(e)}
-        finally:
-            os.environ.pop("AR_GROUPS", None)
     if not args.no_cpu_baseline and args.cpu_secs > 0 and world == 1:  # a reported baseline, timed on rank 0 at N=1 only
         left = args.deadline + 60.0 - (time.perf_counter() - T_START)
         if left > args.cpu_secs + 15.0:
