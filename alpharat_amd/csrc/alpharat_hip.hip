@@ -30,6 +30,7 @@
 #include "slot_layout.h"
 #include "dev_gather8.h"
 #include "dev_gather2.h"
+#include "dev_gather4.h"
 #include "dev_backup16.h"
 #include "zig_norm_tables.inc"
 
@@ -405,6 +406,147 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
             if (ol == 0) base = atomicAdd(queue_count, o.b_nn);
             base = oct_pick(base, 0);
             for (uint32_t j = ol; j < o.b_nn; j += 8) {
+                LeafReq<NW> r;
+                r.st = m.leaves()[j];
+                r.slot = i;
+                r.pad = 0;
+                queue[base + j] = r;
+            }
+        }
+        if (ol == 0) {
+            S.hi = o.hi;
+            S.node_count = o.node_count;
+            S.new_nodes += o.d_new;
+            S.nv_gather += o.d_visits;
+            S.n_proc = o.n_proc;
+            S.n_coll = o.n_coll;
+            S.b_nn = o.b_nn;
+            S.b_term = o.b_term;
+            S.b_coll = o.b_coll;
+            S.batch_active = o.batch_active;
+            S.eval_base = base;
+            S.rng = sh.rng;
+            S.gather_pending = 0;
+            S.g_rounds = o.rounds;
+            if (o.error) S.error = o.error;
+        }
+    }
+    if (ol == 0) {
+        if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
+        S.status = tag_status(status, phase);
+    }
+}
+
+// The same gather with four lanes per game (dev_gather4.h): a wavefront holds sixteen games. Launched with ceil(n / 16)
+// blocks of 64 threads, two wavefronts per SIMD.
+template <int NW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gather4(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
+                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
+                                                uint32_t phase, uint32_t accept_ready, const uint32_t* list,
+                                                const uint32_t* list_n) {
+    const uint32_t ol = threadIdx.x & 3u;
+    uint32_t i = first + blockIdx.x * 16u + (threadIdx.x >> 2);
+    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
+    if (list != nullptr) {  // (k_partition) the games list[0 .. *list_n)
+        uint32_t n_list = *list_n;
+        if (n_list > gridDim.x * 16u) n_list = gridDim.x * 16u;  // (k_partition caps the list at the grid's size)
+        if (blockIdx.x * 16u >= n_list) return;  // whole block beyond the list
+        const uint32_t j = blockIdx.x * 16u + (threadIdx.x >> 2);
+        i = j < n_list ? list[j] : 0xFFFFFFFFu;
+    }
+    bool run = i < n_slots;
+    if (run) {
+        const uint32_t st = slots[i].status;
+        run = st == SLOT_ACTIVE || st == accept_ready;
+    }
+    const uint32_t ii = i < n_slots ? i : first;  // idle octets read a valid slot and store nothing
+    Slot<NW>& S = slots[ii];
+    OctMem<NW> m;
+    m.stats = (NodeStats*)(B.arena + S.stats_off);
+    m.kids = (NodeKids*)(B.arena + S.kids_off);
+    m.scratch = B.scratch;
+    m.maze = B.maze;
+    if (B.maze_stage) {
+        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
+        m.maze = (const uint8_t*)lds_maze;  // (the barrier below, in front of the rounds, orders these writes)
+    }
+    m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
+    m.maze_off = S.board.maze_off;
+    m.proc_off = (uint32_t)B.L.proc_off;
+    m.coll_off = (uint32_t)B.L.coll_off;
+    m.levels_off = (uint32_t)B.L.levels_off;
+    m.leaf_off = (uint32_t)B.L.leaf_off;
+    m.coll_cap = B.L.coll_cap;
+    m.max_depth = B.L.max_depth;
+    const Board board = S.board;
+    __shared__ OctShared<NW> shared[16];
+    __shared__ OutcomeTable otab;
+    outcome_table_fill(otab);
+    OctShared<NW>& sh = shared[threadIdx.x >> 2];
+    Quad<NW> o;
+    o.done = true;
+    o.alloc_left = 0;
+    o.error = 0;
+    o.d_new = o.d_visits = 0;
+    o.rounds = 0;
+    o.batch_active = S.batch_active;
+    bool stalled = false;
+    // a batch that was already gathered and still waits for its backup is left alone
+    const bool begin = run && o.batch_active == 0;
+    if (begin) {
+        // gather_begin (dev_search.h)
+        o.hi = S.hi;
+        o.cap = S.cap;
+        o.root = S.root;
+        o.node_count = S.node_count;
+        const uint32_t remaining = S.remaining;
+        o.batch = remaining < cfg.batch_size ? remaining : cfg.batch_size;
+        if (o.hi + o.batch > o.cap) {
+            stalled = true;
+        } else {
+            o.left = (long long)(int32_t)collisions_left(o.node_count, cfg);
+            o.n_proc = o.n_coll = o.b_nn = o.b_term = o.b_coll = 0;
+            o.depth = 0;
+            o.node = 0;
+            o.mask = 0;
+            o.omap0 = o.omap1 = 0;
+            o.pick_mv = 0;
+            o.have_pick = false;
+            o.work = S.st;
+            sh.rng = S.rng;  // (all eight lanes store the same values: see best_of5)
+            sh.root_st = S.st;
+            o.n1 = o.n2 = 0;
+            o.forced = 0;
+            for (int k = 0; k < 2; ++k) {
+                o.sc[k] = o.util[k] = o.num[k] = 0.0f;
+                o.ns[k] = o.add[k] = o.nif0[k] = 0;
+            }
+            for (int k = 0; k < 8; ++k) {
+                o.kid[k] = NIL;
+                o.vtp[k] = 0;
+            }
+            o.sc5 = o.util5 = o.num5 = 0.0f;
+            o.ns5 = o.add5 = o.nif05 = o.forced5 = 0;
+            o.done = false;
+        }
+    }
+    __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
+    for (uint32_t guard = 0; guard < (1u << 22); ++guard) {  // (every game's gather ends; the bound is a fuse)
+        if (!__any(!o.done)) break;
+        gather4_round(o, sh, otab, board, m, cfg, ol);
+    }
+    __syncthreads();
+    if (!run) return;
+    if (begin && !stalled && !o.done) o.error = 8;  // the fuse blew
+    uint32_t status = SLOT_ACTIVE;
+    if (stalled) status = SLOT_STALL;
+    if (begin && !stalled) {
+        uint32_t base = 0;
+        const bool complete = o.done && o.batch_active != 0;
+        if (complete && queue != nullptr && o.b_nn > 0) {
+            if (ol == 0) base = atomicAdd(queue_count, o.b_nn);
+            base = quad_get<0>(base);
+            for (uint32_t j = ol; j < o.b_nn; j += 4) {
                 LeafReq<NW> r;
                 r.st = m.leaves()[j];
                 r.slot = i;
@@ -1580,6 +1722,7 @@ struct ArenaHold {
 static bool default_gather8(uint32_t) { return true; }
 // its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
 static bool default_gather2(uint32_t) { return false; }
+static bool default_gather4(uint32_t) { return false; }
 static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
 static bool default_hybrid(uint32_t) { return false; }
 // measured (BASELINE config 2: 5x5, 1000 sims, 4096 games: 71.1 M vs 41.5 M simulations/s through the split pipeline;
@@ -1643,6 +1786,7 @@ struct Engine {
     bool use_queue() const { return net != nullptr || uniform_queue; }
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     bool gather2 = false; // network path: the two-lanes-per-game gather (k_gather2)
+    bool gather4 = false;  // network path: the four-lanes-per-game gather (k_gather4)
     bool gather_mixed = false;  // odd groups of games walk with k_gather2, even groups with k_gather8 (AR_GATHER=mixed)
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
     // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
@@ -1746,6 +1890,8 @@ struct Engine {
         gather2 = default_gather2(S);
         if (const char* e = getenv("AR_GATHER")) gather2 = std::string(e) == "pair";
         if (const char* e = getenv("AR_GATHER")) gather_mixed = std::string(e) == "mixed";
+        gather4 = default_gather4(S);
+        if (const char* e = getenv("AR_GATHER")) gather4 = std::string(e) == "quad";
         if (gather_mixed) gather8 = true;
         if (const char* e = getenv("AR_HEAVY_FRAC"))
             if (atof(e) > 0.0 && atof(e) < 1.0) heavy_frac = (float)atof(e);
@@ -1766,7 +1912,7 @@ struct Engine {
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
-        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = gather2 = gather_mixed = hybrid = false;  // k_gather8 / k_gather2 address scratch with 32-bit offsets
+        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = gather2 = gather4 = gather_mixed = hybrid = false;  // k_gather8 / k_gather2 / k_gather4 address scratch with 32-bit offsets
         // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
         size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
         {
@@ -1962,7 +2108,10 @@ struct Engine {
                                (const uint32_t*)(part_ctrl.p + 1));
             HIP_TRY(hipStreamWaitEvent(g.stream, ev_heavy, 0));
             hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, g.stream, part_ctrl.p, heavy_frac, cap);
-        } else if (gather2 || (gather_mixed && (gi & 1)))
+        } else if (gather4)
+            hipLaunchKernelGGL(k_gather4<NW>, dim3((n + 15) / 16), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q, qc,
+                               g.first, phase, ready, no_list, no_list);
+        else if (gather2 || (gather_mixed && (gi & 1)))
         {
             if (gather_rounds != 0xFFFFFFFFu)
                 hipLaunchKernelGGL((k_gather2<NW, true>), dim3((n + 31) / 32), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
@@ -2587,7 +2736,7 @@ struct SelfPlaySession : SessionBase {
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = eng.backup_lanes = (uint32_t)atoi(e);
         if (const char* e = getenv("AR_BACKUP_LANES"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.backup_lanes = (uint32_t)atoi(e);
-        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.hybrid = false;  // the round limit parks the walk: lane and pair kernels only
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.gather4 = eng.hybrid = false;  // the round limit parks the walk: lane and pair kernels only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();
