@@ -384,6 +384,9 @@ def main() -> int:
         import subprocess
 
         try:
+            from alpharat_amd.sampling import release_device_memory
+
+            release_device_memory(local_rank)  # (the arena block this process keeps cached between sessions)
             left = max(args.deadline - (time.perf_counter() - T_START), 60.0)
             r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--full-launch-child", "--evaluator", args.evaluator,
                                 "--resident", str(args.resident), "--batch-steps", str(args.batch_steps)],
