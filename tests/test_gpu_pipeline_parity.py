@@ -109,6 +109,28 @@ def test_network_selfplay_records_bit_exact(name, blob, sims, search, n_games, n
         assert want["total_nn_evals"] > 0 and max(ev.backend.sizes) <= 16
 
 
+@pytest.mark.parametrize("shape", ["quad", "pair", "lane"])
+def test_network_selfplay_other_gather_shapes_bit_exact_vs_oracle(shape, monkeypatch):
+    """The gather kernels with four, two and one lane per game (AR_GATHER; eight lanes is the default the cases above run
+    on) against the oracle at record level: tuned constants + noise, 600 simulations, more games than slots. (That all
+    shapes produce the same records as each other is test_selfplay_records_do_not_depend_on_scheduling.)"""
+    from alpharat_amd.sampling import rust_self_play
+
+    monkeypatch.setenv("AR_GATHER", shape)
+    games = {}
+    stats = rust_self_play(width=7, height=7, cheese_count=10, max_turns=50, num_games=40, simulations=600, batch_size=16,
+                           output_dir=None, seed=4, concurrent_games=32, weights_path=str(GOLD / "mlp_7x7_h256.arnet"),
+                           on_game=lambda g: games.__setitem__(g["game_index"], g), **TUNED)
+    monkeypatch.delenv("AR_GATHER")
+    assert stats.total_games == 40 and stats.total_nn_evals > 0
+    ev = HipEvaluator(GOLD / "mlp_7x7_h256.arnet", 7, 7, 50)
+    cfg = O.make_config(**TUNED)
+    for i in (0, 39):
+        want = O.play_game(O.Game(7, 7, 50).random_cheese(10, True, 4 + i), cfg, 600, 16, 0xA1FA0000 + 4 + i, backend=4,
+                           net=ev.backend, game_index=i)
+        _check_game(games[i], want)
+
+
 def test_network_selfplay_with_eval_cache_bit_exact_vs_oracle():
     """cache_size > 0 (k_cache_probe / k_cache_fill between the gather and the network): hits must return the bits
     the network would compute again, so records still equal the oracle's (which evaluates every leaf)."""
