@@ -310,6 +310,29 @@ def test_selfplay_generated_mazes_bit_exact(maze_type, w, h, cheese, turns, extr
     assert seen_wall and seen_mud
 
 
+@pytest.mark.parametrize("shape", ["quad", "pair", "lane"])
+def test_selfplay_over_64_cells_on_the_other_gather_shapes(shape, monkeypatch):
+    """Boards above 64 cells use the four-word cheese masks (the NW = 4 kernel instances), per-game generated mazes
+    keep the cost tables in global memory instead of LDS: the four-, two- and one-lane gathers on that path
+    (AR_GATHER; SmartUniform runs through the split pipeline at this size) against the oracle."""
+    from alpharat_amd.sampling import rust_self_play
+
+    monkeypatch.setenv("AR_GATHER", shape)
+    monkeypatch.setenv("AR_UNIFORM", "queue")
+    games = []
+    stats = rust_self_play(width=11, height=9, cheese_count=12, max_turns=60, num_games=12, simulations=150, batch_size=8,
+                           output_dir=None, seed=0, concurrent_games=8, maze_type="random", on_game=games.append,
+                           wall_density=0.8, mud_density=0.2, maze_symmetric=True)
+    monkeypatch.delenv("AR_GATHER")
+    monkeypatch.delenv("AR_UNIFORM")
+    assert stats.total_games == 12
+    cfg = O.make_config()
+    for g in games:
+        i = g["game_index"]
+        og = O.Game(11, 9, 60).random_maze(0.8, 0.2, True, i).random_cheese(12, True, i)
+        _check_game(g, O.play_game(og, cfg, 150, 8, 0xA1FA0000 + i))
+
+
 def test_selfplay_generated_mazes_with_network_uses_each_games_maze():
     """With a network the first-layer maze constants are refreshed for every slot that gets a new game:
     the root prior recorded at move 0 equals the network's policy for that game's own maze."""
