@@ -29,8 +29,6 @@
 #include "npz_writer.h"
 #include "slot_layout.h"
 #include "dev_gather8.h"
-#include "dev_gather2.h"
-#include "dev_gather4.h"
 #include "dev_backup16.h"
 #include "zig_norm_tables.inc"
 
@@ -147,8 +145,7 @@ __device__ inline void slot_at_home(Slot<NW>& s, const Bases& B, uint32_t slot) 
     const long long base = (long long)slot * (long long)arena_bytes(B.cap0);
     s.cap = B.cap0;
     s.stats_off = base;
-    s.kids_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
-    s.fwd_off = s.kids_off + (long long)B.cap0 * (long long)sizeof(NodeKids);
+    s.fwd_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
     s.pool_blk = 0;
 }
 template <int NW>
@@ -157,8 +154,7 @@ __device__ inline void slot_at_block(Slot<NW>& s, const Bases& B, int cls, uint3
     const long long base = B.pool.off[cls] + (long long)idx * (long long)arena_bytes(cap);
     s.cap = cap;
     s.stats_off = base;
-    s.kids_off = base + (long long)cap * (long long)sizeof(NodeStats);
-    s.fwd_off = s.kids_off + (long long)cap * (long long)sizeof(NodeKids);
+    s.fwd_off = base + (long long)cap * (long long)sizeof(NodeStats);
     s.pool_blk = ((uint32_t)(cls + 1) << 24) | idx;
 }
 // the arena a slot leaves behind: pool blocks go to the return list, host-grown ones are flagged
@@ -256,21 +252,15 @@ template <int NW>
 __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t max_rounds,
                                                uint32_t lanes, uint32_t first, uint32_t phase,
-                                               uint32_t accept_ready, const uint32_t* list, const uint32_t* list_n) {
-    // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64);
-    // with a `list` (k_partition): the games list[0 .. *list_n)
+                                               uint32_t accept_ready) {
+    // slots [first, n_slots) -- one group of games; `lanes` games per wavefront (<= 64)
     __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
     if (B.maze_stage) {
         for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
         __syncthreads();
     }
     if (threadIdx.x >= lanes) return;
-    uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
-    if (list != nullptr) {
-        const uint32_t j = blockIdx.x * lanes + threadIdx.x;
-        if (j >= *list_n) return;
-        i = list[j];
-    }
+    const uint32_t i = first + blockIdx.x * lanes + threadIdx.x;
     if (i >= n_slots) return;
     {
         const uint32_t st = slots[i].status;
@@ -303,18 +293,10 @@ __global__ void __launch_bounds__(64) k_gather(Slot<NW>* slots, uint32_t n_slots
 template <int NW, int WPE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_gather8(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                 LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready, const uint32_t* list,
-                                                const uint32_t* list_n) {
+                                                uint32_t phase, uint32_t accept_ready) {
     const uint32_t ol = threadIdx.x & 7u;
-    uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
+    const uint32_t i = first + blockIdx.x * 8u + (threadIdx.x >> 3);
     __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
-    if (list != nullptr) {  // (k_partition) the games list[0 .. *list_n)
-        uint32_t n_list = *list_n;
-        if (n_list > gridDim.x * 8u) n_list = gridDim.x * 8u;  // (k_partition caps the list at the grid's size)
-        if (blockIdx.x * 8u >= n_list) return;  // whole block beyond the list
-        const uint32_t j = blockIdx.x * 8u + (threadIdx.x >> 3);
-        i = j < n_list ? list[j] : 0xFFFFFFFFu;
-    }
     bool run = i < n_slots;
     if (run) {
         const uint32_t st = slots[i].status;
@@ -324,7 +306,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     Slot<NW>& S = slots[ii];
     OctMem<NW> m;
     m.stats = (NodeStats*)(B.arena + S.stats_off);
-    m.kids = (NodeKids*)(B.arena + S.kids_off);
     m.scratch = B.scratch;
     m.maze = B.maze;
     if (B.maze_stage) {
@@ -437,432 +418,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     }
 }
 
-// The same gather with four lanes per game (dev_gather4.h): a wavefront holds sixteen games. Launched with ceil(n / 16)
-// blocks of 64 threads, two wavefronts per SIMD.
-template <int NW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gather4(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
-                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready, const uint32_t* list,
-                                                const uint32_t* list_n) {
-    const uint32_t ol = threadIdx.x & 3u;
-    uint32_t i = first + blockIdx.x * 16u + (threadIdx.x >> 2);
-    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
-    if (list != nullptr) {  // (k_partition) the games list[0 .. *list_n)
-        uint32_t n_list = *list_n;
-        if (n_list > gridDim.x * 16u) n_list = gridDim.x * 16u;  // (k_partition caps the list at the grid's size)
-        if (blockIdx.x * 16u >= n_list) return;  // whole block beyond the list
-        const uint32_t j = blockIdx.x * 16u + (threadIdx.x >> 2);
-        i = j < n_list ? list[j] : 0xFFFFFFFFu;
-    }
-    bool run = i < n_slots;
-    if (run) {
-        const uint32_t st = slots[i].status;
-        run = st == SLOT_ACTIVE || st == accept_ready;
-    }
-    const uint32_t ii = i < n_slots ? i : first;  // idle octets read a valid slot and store nothing
-    Slot<NW>& S = slots[ii];
-    OctMem<NW> m;
-    m.stats = (NodeStats*)(B.arena + S.stats_off);
-    m.kids = (NodeKids*)(B.arena + S.kids_off);
-    m.scratch = B.scratch;
-    m.maze = B.maze;
-    if (B.maze_stage) {
-        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
-        m.maze = (const uint8_t*)lds_maze;  // (the barrier below, in front of the rounds, orders these writes)
-    }
-    m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
-    m.maze_off = S.board.maze_off;
-    m.proc_off = (uint32_t)B.L.proc_off;
-    m.coll_off = (uint32_t)B.L.coll_off;
-    m.levels_off = (uint32_t)B.L.levels_off;
-    m.leaf_off = (uint32_t)B.L.leaf_off;
-    m.coll_cap = B.L.coll_cap;
-    m.max_depth = B.L.max_depth;
-    const Board board = S.board;
-    __shared__ OctShared<NW> shared[16];
-    __shared__ OutcomeTable otab;
-    outcome_table_fill(otab);
-    OctShared<NW>& sh = shared[threadIdx.x >> 2];
-    Quad<NW> o;
-    o.done = true;
-    o.alloc_left = 0;
-    o.error = 0;
-    o.d_new = o.d_visits = 0;
-    o.rounds = 0;
-    o.batch_active = S.batch_active;
-    bool stalled = false;
-    // a batch that was already gathered and still waits for its backup is left alone
-    const bool begin = run && o.batch_active == 0;
-    if (begin) {
-        // gather_begin (dev_search.h)
-        o.hi = S.hi;
-        o.cap = S.cap;
-        o.root = S.root;
-        o.node_count = S.node_count;
-        const uint32_t remaining = S.remaining;
-        o.batch = remaining < cfg.batch_size ? remaining : cfg.batch_size;
-        if (o.hi + o.batch > o.cap) {
-            stalled = true;
-        } else {
-            o.left = (long long)(int32_t)collisions_left(o.node_count, cfg);
-            o.n_proc = o.n_coll = o.b_nn = o.b_term = o.b_coll = 0;
-            o.depth = 0;
-            o.node = 0;
-            o.mask = 0;
-            o.omap0 = o.omap1 = 0;
-            o.pick_mv = 0;
-            o.have_pick = false;
-            o.work = S.st;
-            sh.rng = S.rng;  // (all eight lanes store the same values: see best_of5)
-            sh.root_st = S.st;
-            o.n1 = o.n2 = 0;
-            o.forced = 0;
-            for (int k = 0; k < 2; ++k) {
-                o.sc[k] = o.util[k] = o.num[k] = 0.0f;
-                o.ns[k] = o.add[k] = o.nif0[k] = 0;
-            }
-            for (int k = 0; k < 8; ++k) {
-                o.kid[k] = NIL;
-                o.vtp[k] = 0;
-            }
-            o.sc5 = o.util5 = o.num5 = 0.0f;
-            o.ns5 = o.add5 = o.nif05 = o.forced5 = 0;
-            o.done = false;
-        }
-    }
-    __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
-    for (uint32_t guard = 0; guard < (1u << 22); ++guard) {  // (every game's gather ends; the bound is a fuse)
-        if (!__any(!o.done)) break;
-        gather4_round(o, sh, otab, board, m, cfg, ol);
-    }
-    __syncthreads();
-    if (!run) return;
-    if (begin && !stalled && !o.done) o.error = 8;  // the fuse blew
-    uint32_t status = SLOT_ACTIVE;
-    if (stalled) status = SLOT_STALL;
-    if (begin && !stalled) {
-        uint32_t base = 0;
-        const bool complete = o.done && o.batch_active != 0;
-        if (complete && queue != nullptr && o.b_nn > 0) {
-            if (ol == 0) base = atomicAdd(queue_count, o.b_nn);
-            base = quad_get<0>(base);
-            for (uint32_t j = ol; j < o.b_nn; j += 4) {
-                LeafReq<NW> r;
-                r.st = m.leaves()[j];
-                r.slot = i;
-                r.pad = 0;
-                queue[base + j] = r;
-            }
-        }
-        if (ol == 0) {
-            S.hi = o.hi;
-            S.node_count = o.node_count;
-            S.new_nodes += o.d_new;
-            S.nv_gather += o.d_visits;
-            S.n_proc = o.n_proc;
-            S.n_coll = o.n_coll;
-            S.b_nn = o.b_nn;
-            S.b_term = o.b_term;
-            S.b_coll = o.b_coll;
-            S.batch_active = o.batch_active;
-            S.eval_base = base;
-            S.rng = sh.rng;
-            S.gather_pending = 0;
-            S.g_rounds = o.rounds;
-            if (o.error) S.error = o.error;
-        }
-    }
-    if (ol == 0) {
-        if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
-        S.status = tag_status(status, phase);
-    }
-}
-
-// The same gather with two lanes per game (dev_gather2.h): a wavefront holds 32 games, a pair of lanes -- one per
-// player -- walks one tree. Launched with ceil(n / 32) blocks of 64 threads, two wavefronts per SIMD (256 VGPRs).
-// All wavefronts of a launch are resident at once, so the launch lasts as long as its longest walk: after `max_rounds`
-// rounds the games still walking are parked (PairParked) and continue in the next launch.
-// (LIMIT: the instance with the park / resume code; the plain one has no spills)
-template <int NW, bool LIMIT>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gather2(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
-                                                LeafReq<NW>* queue, uint32_t* queue_count, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready, uint32_t max_rounds) {
-    static_assert(sizeof(PairParked<NW>) <= PAIR_PARK_BYTES + sizeof(State<NW>), "slot_layout.h reserves the parked gather");
-#if defined(AR_STATS)
-    const unsigned long long clk_entry = wall_clock64();
-#endif
-    const uint32_t p = threadIdx.x & 1u;
-    const uint32_t i = first + blockIdx.x * 32u + (threadIdx.x >> 1);
-    __shared__ uint32_t lds_maze[MAZE_STAGE_BYTES / 4];
-    bool run = i < n_slots;
-    if (run) {
-        const uint32_t st = slots[i].status;
-        run = st == SLOT_ACTIVE || st == accept_ready;
-    }
-    const uint32_t ii = i < n_slots ? i : first;  // idle pairs read a valid slot and store nothing
-    Slot<NW>& S = slots[ii];
-    OctMem<NW> m;
-    m.stats = (NodeStats*)(B.arena + S.stats_off);
-    m.kids = (NodeKids*)(B.arena + S.kids_off);
-    m.scratch = B.scratch;
-    m.maze = B.maze;
-    if (B.maze_stage) {
-        for (uint32_t w = threadIdx.x; w < B.maze_stage / 4; w += blockDim.x) lds_maze[w] = ((const uint32_t*)B.maze)[w];
-        m.maze = (const uint8_t*)lds_maze;  // (the barrier below, in front of the rounds, orders these writes)
-    }
-    m.s_off = (uint32_t)((size_t)ii * B.L.total);  // (setup() keeps all games' scratch below 4 GB for this kernel)
-    m.maze_off = S.board.maze_off;
-    m.proc_off = (uint32_t)B.L.proc_off;
-    m.coll_off = (uint32_t)B.L.coll_off;
-    m.levels_off = (uint32_t)B.L.levels_off;
-    m.leaf_off = (uint32_t)B.L.leaf_off;
-    m.coll_cap = B.L.coll_cap;
-    m.max_depth = B.L.max_depth;
-    PairParked<NW>& park = *(PairParked<NW>*)(B.scratch + ((size_t)ii * B.L.total + B.L.glane_off));
-    const Board board = S.board;
-    __shared__ PairShared<NW> shared[32];
-    __shared__ OutcomeTable otab;
-    outcome_table_fill(otab);
-    PairShared<NW>& sh = shared[threadIdx.x >> 1];
-    const uint32_t q0 = p ? 4u : 0u, qn = p ? 3u : 4u;  // this lane's quarters of a 25-entry table
-    Pair<NW> o;
-    o.done = true;
-    o.alloc_left = 0;
-    o.error = 0;
-    o.d_new = o.d_visits = 0;
-    o.rounds = 0;
-    o.batch_active = S.batch_active;
-    bool stalled = false;
-    // a batch that was already gathered and still waits for its backup is left alone
-    const bool walk = run && o.batch_active == 0;
-    const bool resume = LIMIT && walk && S.gather_pending != 0;
-    const bool begin = walk && !resume;
-    if (walk) {
-        o.hi = S.hi;
-        o.cap = S.cap;
-        o.root = S.root;
-        o.node_count = S.node_count;
-        if (p == 0) pair_rng_store(sh.rng, S.rng);
-        sh.root_st = S.st;  // (both lanes store the same values and read back their own)
-    }
-    if (begin) {
-        // gather_begin (dev_search.h)
-        const uint32_t remaining = S.remaining;
-        o.batch = remaining < cfg.batch_size ? remaining : cfg.batch_size;
-        if (o.hi + o.batch > o.cap) {
-            stalled = true;
-        } else {
-            o.left = (long long)(int32_t)collisions_left(o.node_count, cfg);
-            o.n_proc = o.n_coll = o.b_nn = o.b_term = o.b_coll = 0;
-            o.depth = 0;
-            o.node = 0;
-            o.mask = 0;
-            o.omap0 = o.omap1 = 0;
-            o.pick_mv = 0;
-            o.have_pick = false;
-            o.work = S.st;
-            o.h.n = 0;
-            o.h.forced = 0;
-            for (int k = 0; k < 5; ++k) {
-                o.h.score[k] = o.h.util[k] = o.h.num[k] = 0.0f;
-                o.h.ns[k] = o.h.add[k] = o.h.nif0[k] = 0;
-            }
-            o.done = false;
-        }
-    }
-    if constexpr (LIMIT) if (resume) {
-        o.batch = park.batch;
-        o.depth = park.depth;
-        o.node = park.node;
-        o.mask = park.mask;
-        o.omap0 = park.omap0;
-        o.omap1 = park.omap1;
-        o.pick_mv = park.pick_mv;
-        o.have_pick = park.have_pick != 0;
-        o.alloc_left = park.alloc_left;
-        o.n_proc = park.n_proc;
-        o.n_coll = park.n_coll;
-        o.b_nn = park.b_nn;
-        o.b_term = park.b_term;
-        o.b_coll = park.b_coll;
-        o.error = park.error;
-        o.left = park.left;
-        o.work = park.work;
-        half_copy(o.h, park.h[p]);
-        volatile u32x4* kid4 = (volatile u32x4*)sh.kid;
-        volatile u32x4* vtp4 = (volatile u32x4*)sh.vtp;
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (j < qn) {
-                kid4[q0 + j] = ((const u32x4*)park.kid)[q0 + j];
-                vtp4[q0 + j] = ((const u32x4*)park.vtp)[q0 + j];
-            }
-        }
-        o.done = false;
-    }
-    __syncthreads();  // (one wavefront: the LDS writes above are visible to its other lanes)
-    const uint32_t fuse = LIMIT && max_rounds < (1u << 22) ? max_rounds : (1u << 22);
-#if defined(AR_STATS)
-    const unsigned long long clk_loop = wall_clock64();
-    uint32_t wave_rounds = 0;
-#endif
-    for (uint32_t r = 0; r < fuse; ++r) {  // (every game's gather ends; without a round limit the bound is a fuse)
-        if (!__any(!o.done)) break;
-        gather2_round(o, sh, otab, board, m, cfg, p);
-#if defined(AR_STATS)
-        wave_rounds += 1;
-#endif
-    }
-#if defined(AR_STATS)
-    if (threadIdx.x == 0) {  // [0] wavefronts, [1] their rounds, [2] loop ticks (100 MHz), [3] longest loop, [4] ticks from kernel entry to the loop
-        const unsigned long long dt = wall_clock64() - clk_loop;
-        atomicAdd(&ar::g_gather_clk[0], 1ULL);
-        atomicAdd(&ar::g_gather_clk[1], (unsigned long long)wave_rounds);
-        atomicAdd(&ar::g_gather_clk[2], dt);
-        atomicMax(&ar::g_gather_clk[3], dt);
-        atomicAdd(&ar::g_gather_clk[4], clk_loop - clk_entry);
-        atomicAdd(&ar::g_gather_clk[8 + (wave_rounds / 16 < 31 ? wave_rounds / 16 : 31)], 1ULL);   // wavefronts by rounds / 16
-        atomicAdd(&ar::g_gather_clk[40 + (wave_rounds / 16 < 31 ? wave_rounds / 16 : 31)], dt);    // their loop ticks
-    }
-#endif
-    __syncthreads();
-    if (!run) return;
-    const bool cut = walk && !stalled && !o.done;  // still walking at the limit
-    if (cut && (!LIMIT || max_rounds >= (1u << 22))) o.error = 8;  // the fuse blew
-    uint32_t status = SLOT_ACTIVE;
-    if (stalled) status = SLOT_STALL;
-    if (walk && !stalled) {
-        uint32_t base = 0;
-        const bool complete = o.done && o.batch_active != 0;
-        if (complete && queue != nullptr && o.b_nn > 0) {
-            if (p == 0) base = atomicAdd(queue_count, o.b_nn);
-            const uint32_t other = pair_swap(base);
-            base = p ? other : base;
-            for (uint32_t j = p; j < o.b_nn; j += 2) {
-                LeafReq<NW> r;
-                r.st = m.leaves()[j];
-                r.slot = i;
-                r.pad = 0;
-                queue[base + j] = r;
-            }
-        }
-        if constexpr (LIMIT) if (cut && o.error == 0) {
-            half_copy(park.h[p], o.h);
-            volatile u32x4* kid4 = (volatile u32x4*)sh.kid;
-            volatile u32x4* vtp4 = (volatile u32x4*)sh.vtp;
-            for (uint32_t j = 0; j < 4; ++j) {
-                if (j < qn) {
-                    ((u32x4*)park.kid)[q0 + j] = kid4[q0 + j];
-                    ((u32x4*)park.vtp)[q0 + j] = vtp4[q0 + j];
-                }
-            }
-        }
-        if (p == 0) {
-            S.hi = o.hi;
-            S.node_count = o.node_count;
-            S.new_nodes += o.d_new;
-            S.nv_gather += o.d_visits;
-            S.rng = pair_rng_load(sh.rng);
-            if (LIMIT && cut && o.error == 0) {
-                park.batch = o.batch;
-                park.depth = o.depth;
-                park.node = o.node;
-                park.mask = o.mask;
-                park.omap0 = o.omap0;
-                park.omap1 = o.omap1;
-                park.pick_mv = o.pick_mv;
-                park.have_pick = o.have_pick ? 1u : 0u;
-                park.alloc_left = o.alloc_left;
-                park.n_proc = o.n_proc;
-                park.n_coll = o.n_coll;
-                park.b_nn = o.b_nn;
-                park.b_term = o.b_term;
-                park.b_coll = o.b_coll;
-                park.error = o.error;
-                park.left = o.left;
-                park.work = o.work;
-                S.g_rounds = (resume ? S.g_rounds : 0u) + o.rounds;
-                S.gather_pending = 1;
-            } else {
-                S.n_proc = o.n_proc;
-                S.n_coll = o.n_coll;
-                S.b_nn = o.b_nn;
-                S.b_term = o.b_term;
-                S.b_coll = o.b_coll;
-                S.batch_active = o.batch_active;
-                S.eval_base = base;
-                S.g_rounds = (resume ? S.g_rounds : 0u) + o.rounds;
-                S.gather_pending = 0;
-                if (o.error) S.error = o.error;
-            }
-        }
-    }
-    if (p == 0) {
-        if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
-        S.status = tag_status(status, phase);
-    }
-}
-
-// Two gather kernels side by side: games whose last gather took more than `ctrl[0]` rounds (deep trees, many
-// collisions: the few that decide how long a lane-per-game launch lasts) go to the eight-lanes-per-game kernel, which
-// finishes a long walk several times sooner; the rest stay one per lane. k_partition splits the runnable games of
-// this step into the two lists and histograms their round counts; k_threshold turns the histogram into the cut for
-// the NEXT step (the `frac` largest). ctrl: [0] cut, [1] light count, [2] heavy count, [8..8+64) histogram.
-enum { PART_BINS = 64, PART_BIN_W = 8 };
-template <int NW>
-__global__ void k_partition(const Slot<NW>* slots, uint32_t n_slots, uint32_t first, uint32_t accept_ready,
-                            uint32_t* ctrl, uint32_t* light, uint32_t* heavy, uint32_t heavy_cap) {
-    const uint32_t i = first + blockIdx.x * blockDim.x + threadIdx.x;
-    bool runnable = false, is_heavy = false;
-    if (i < n_slots) {
-        const uint32_t st = slots[i].status;
-        runnable = (st == SLOT_ACTIVE || st == accept_ready) && slots[i].batch_active == 0;
-        if (runnable) {
-            const uint32_t r = slots[i].g_rounds;
-            is_heavy = r > ctrl[0];
-            const uint32_t b = r / PART_BIN_W;
-            atomicAdd(&ctrl[8 + (b < PART_BINS ? b : PART_BINS - 1)], 1u);
-        }
-    }
-    const unsigned long long ml = __ballot(runnable && !is_heavy), mh = __ballot(runnable && is_heavy);
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t bl = 0, bh = 0;
-    if (lane == 0) {
-        if (ml) bl = atomicAdd(&ctrl[1], (uint32_t)__popcll(ml));
-        if (mh) bh = atomicAdd(&ctrl[2], (uint32_t)__popcll(mh));
-    }
-    bl = (uint32_t)__shfl((int)bl, 0, 64);
-    bh = (uint32_t)__shfl((int)bh, 0, 64);
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    if (runnable && !is_heavy) light[bl + (uint32_t)__popcll(ml & below)] = i;
-    if (runnable && is_heavy) {
-        const uint32_t pos = bh + (uint32_t)__popcll(mh & below);
-        if (pos < heavy_cap) heavy[pos] = i;
-        else light[atomicAdd(&ctrl[1], 1u)] = i;  // the heavy kernel's grid is full: one per lane after all
-    }
-}
-__global__ void k_threshold(uint32_t* ctrl, float frac, uint32_t max_heavy) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t total = 0;
-    for (int b = 0; b < PART_BINS; ++b) total += ctrl[8 + b];
-    uint32_t want = (uint32_t)((float)total * frac);
-    if (want > max_heavy) want = max_heavy;
-    uint32_t above = 0;
-    int cut = PART_BINS;  // bins >= cut are heavy
-    for (int b = PART_BINS - 1; b >= 1; --b) {
-        if (above + ctrl[8 + b] > want) break;
-        above += ctrl[8 + b];
-        cut = b;
-    }
-    ctrl[0] = (uint32_t)cut * PART_BIN_W - 1u;  // heavy: rounds > cut * width - 1, i.e. rounds in bin >= cut
-    ctrl[3] = ctrl[1];  // last step's list sizes and histogram, for AR_PART_DEBUG
-    ctrl[4] = ctrl[2];
-    ctrl[1] = ctrl[2] = 0;
-    for (int b = 0; b < PART_BINS; ++b) {
-        ctrl[8 + PART_BINS + b] = ctrl[8 + b];
-        ctrl[8 + b] = 0;
-    }
-}
-
 template <int NW>
 __global__ void __launch_bounds__(64) k_backup(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B,
                                                const ZigTables* zt, const EvalOut* ev_queue, uint32_t lanes,
@@ -949,9 +504,6 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         const uint4* ss = (const uint4*)m.stats;
         uint4* ds = (uint4*)md.stats;
         for (uint32_t w = lane; w < s.hi * (uint32_t)(sizeof(NodeStats) / 16); w += 64) ds[w] = ss[w];
-        const uint4* sk = (const uint4*)m.kids;
-        uint4* dk = (uint4*)md.kids;
-        for (uint32_t w = lane; w < s.hi * (uint32_t)(sizeof(NodeKids) / 16); w += 64) dk[w] = sk[w];
         if (lane == 0) {
             leave_arena(s, d, B);
             d.status = ready_status;
@@ -1048,22 +600,17 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
         uint32_t ni = NIL;
         if (i < hi) ni = __hip_atomic_load(&m.fwd[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         NodeStats nd;
-        NodeKids kd;
         if (ni != NIL) {
             nd = m.stats[i];
-            kd = m.kids[i];
             nd.h1.parent = i == keep_root ? NIL
                                           : __hip_atomic_load(&m.fwd[nd.h1.parent], __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int c = 0; c < 25; ++c)
-                if (kd.c[c] != NIL)
-                    kd.c[c] = __hip_atomic_load(&m.fwd[kd.c[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nd.c[c] != NIL)
+                    nd.c[c] = __hip_atomic_load(&m.fwd[nd.c[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();  // every lane has read its node before any lane overwrites a source
-        if (ni != NIL) {
-            md.stats[ni] = nd;
-            md.kids[ni] = kd;
-        }
+        if (ni != NIL) md.stats[ni] = nd;
         __syncthreads();
     }
     if (lane == 0) {
@@ -1169,11 +716,11 @@ __global__ void k_pack_done(Slot<NW>* slots, const uint32_t* done_list, uint32_t
 // arena growth: what a stalled slot reports, and its new home once the host has copied the nodes
 struct StallInfo {
     uint32_t slot, cap, hi, need;
-    long long stats_off, kids_off;
+    long long stats_off;
 };
 struct GrowReq {
     uint32_t slot, cap;
-    long long stats_off, kids_off, fwd_off;
+    long long stats_off, fwd_off;
 };
 template <int NW>
 __global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, uint32_t n, StallInfo* out) {
@@ -1186,7 +733,6 @@ __global__ void k_read_stall(const Slot<NW>* slots, const uint32_t* stall_list, 
     o.hi = s.hi;
     o.need = s.need_nodes;
     o.stats_off = s.stats_off;
-    o.kids_off = s.kids_off;
     out[i] = o;
 }
 template <int NW>
@@ -1203,7 +749,6 @@ __global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n, Ba
     s.pool_blk = 0;
     s.cap = req[i].cap;
     s.stats_off = req[i].stats_off;
-    s.kids_off = req[i].kids_off;
     s.fwd_off = req[i].fwd_off;
     s.status = SLOT_ACTIVE;
 }
@@ -1721,10 +1266,7 @@ struct ArenaHold {
 // to one wavefront or none, and still ahead at 65536 once the shared maze sits in LDS and three wavefronts share a SIMD.
 static bool default_gather8(uint32_t) { return true; }
 // its register budget: two wavefronts per SIMD without spills up to 32768 games, three (168 VGPRs) above
-static bool default_gather2(uint32_t) { return false; }
-static bool default_gather4(uint32_t) { return false; }
 static int default_gather8_wpe(uint32_t resident_games) { return resident_games <= 32768u ? 2 : 3; }
-static bool default_hybrid(uint32_t) { return false; }
 // measured (BASELINE config 2: 5x5, 1000 sims, 4096 games: 71.1 M vs 41.5 M simulations/s through the split pipeline;
 // 7x7 / 1897 sims at 65536 games: 1180 M vs 1251 M): few games want k_gather8's wavefront count, many the fused kernel
 static bool default_uniform_queue(uint32_t resident_games) { return resident_games <= 16384u; }
@@ -1785,17 +1327,7 @@ struct Engine {
     bool uniform_queue = false;  // SmartUniform through the split pipeline (leaf queue + k_uniform_eval) instead of k_step_uniform
     bool use_queue() const { return net != nullptr || uniform_queue; }
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
-    bool gather2 = false; // network path: the two-lanes-per-game gather (k_gather2)
-    bool gather4 = false;  // network path: the four-lanes-per-game gather (k_gather4)
-    bool gather_mixed = false;  // odd groups of games walk with k_gather2, even groups with k_gather8 (AR_GATHER=mixed)
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
-    // both kernels at once: the games with the longest walks on eight lanes each, the others one per lane
-    bool hybrid = false;
-    float heavy_frac = 0.15f;
-    DevBuf<uint32_t> part_ctrl, light_list, heavy_list;
-    hipStream_t hstream = nullptr;
-    hipEvent_t ev_part = nullptr, ev_heavy = nullptr;
-    uint32_t hybrid_cap() const { return S / 4 > 8 ? S / 4 : 8; }
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
@@ -1831,12 +1363,6 @@ struct Engine {
         if (ev0) hipEventDestroy(ev0);
         if (ev1) hipEventDestroy(ev1);
         if (ev_order) hipEventDestroy(ev_order);
-        if (hstream) {
-            hipStreamSynchronize(hstream);
-            hipStreamDestroy(hstream);
-        }
-        if (ev_part) hipEventDestroy(ev_part);
-        if (ev_heavy) hipEventDestroy(ev_heavy);
         if (stream) hipStreamDestroy(stream);
     }
 
@@ -1885,34 +1411,13 @@ struct Engine {
         if (const char* e = getenv("AR_GATHER"))
             if (std::string(e).rfind("octet", 0) == 0)
                 gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : std::string(e) == "octet2" ? 2 : gather8_wpe;
-        hybrid = default_hybrid(S);
-        if (const char* e = getenv("AR_GATHER")) hybrid = std::string(e) == "hybrid";
-        gather2 = default_gather2(S);
-        if (const char* e = getenv("AR_GATHER")) gather2 = std::string(e) == "pair";
-        if (const char* e = getenv("AR_GATHER")) gather_mixed = std::string(e) == "mixed";
-        gather4 = default_gather4(S);
-        if (const char* e = getenv("AR_GATHER")) gather4 = std::string(e) == "quad";
-        if (gather_mixed) gather8 = true;
-        if (const char* e = getenv("AR_HEAVY_FRAC"))
-            if (atof(e) > 0.0 && atof(e) < 1.0) heavy_frac = (float)atof(e);
-        if (hybrid && need_queue) {
-            HIP_TRY(part_ctrl.alloc(8 + 2 * PART_BINS));
-            HIP_TRY(light_list.alloc(S));
-            HIP_TRY(heavy_list.alloc(S));
-            std::vector<uint32_t> init(8 + 2 * PART_BINS, 0u);
-            init[0] = 0xFFFFFFFFu;  // nobody is heavy until a histogram says so
-            HIP_TRY(hipMemcpy(part_ctrl.p, init.data(), init.size() * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipStreamCreateWithFlags(&hstream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev_part, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
-        }
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
         HIP_TRY(scratch.alloc((size_t)S * L.total));
-        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = gather2 = gather4 = gather_mixed = hybrid = false;  // k_gather8 / k_gather2 / k_gather4 address scratch with 32-bit offsets
+        if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = false;  // k_gather8 addresses scratch with 32-bit offsets
         // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
         size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
         {
@@ -2092,46 +1597,18 @@ struct Engine {
             }
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used], g.stream));
         }
-        const uint32_t* no_list = nullptr;
-        if (hybrid && groups.size() == 1) {
-            // light games one per lane, heavy games eight lanes each, side by side (k_partition)
-            const uint32_t cap = hybrid_cap();
-            hipLaunchKernelGGL(k_partition<NW>, dim3(grid(n)), dim3(64), 0, g.stream, slots.p, g.end, g.first, ready, part_ctrl.p,
-                               light_list.p, heavy_list.p, cap);
-            HIP_TRY(hipEventRecord(ev_part, g.stream));
-            HIP_TRY(hipStreamWaitEvent(hstream, ev_part, 0));
-            hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((cap + 7) / 8), dim3(64), 0, hstream, slots.p, g.end, cfg, bases(), q, qc,
-                               g.first, phase, ready, (const uint32_t*)heavy_list.p, (const uint32_t*)(part_ctrl.p + 2));
-            HIP_TRY(hipEventRecord(ev_heavy, hstream));
-            hipLaunchKernelGGL(k_gather<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q, qc,
-                               gather_rounds, 64u, g.first, phase, ready, (const uint32_t*)light_list.p,
-                               (const uint32_t*)(part_ctrl.p + 1));
-            HIP_TRY(hipStreamWaitEvent(g.stream, ev_heavy, 0));
-            hipLaunchKernelGGL(k_threshold, dim3(1), dim3(64), 0, g.stream, part_ctrl.p, heavy_frac, cap);
-        } else if (gather4)
-            hipLaunchKernelGGL(k_gather4<NW>, dim3((n + 15) / 16), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q, qc,
-                               g.first, phase, ready, no_list, no_list);
-        else if (gather2 || (gather_mixed && (gi & 1)))
-        {
-            if (gather_rounds != 0xFFFFFFFFu)
-                hipLaunchKernelGGL((k_gather2<NW, true>), dim3((n + 31) / 32), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                                   qc, g.first, phase, ready, gather_rounds);
-            else
-                hipLaunchKernelGGL((k_gather2<NW, false>), dim3((n + 31) / 32), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                                   qc, g.first, phase, ready, gather_rounds);
-        }
-        else if (gather8 && gather8_wpe == 3)
+        if (gather8 && gather8_wpe == 3)
             hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                               qc, g.first, phase, ready, no_list, no_list);
+                               qc, g.first, phase, ready);
         else if (gather8 && gather8_wpe == 4)
             hipLaunchKernelGGL((k_gather8<NW, 4>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                               qc, g.first, phase, ready, no_list, no_list);
+                               qc, g.first, phase, ready);
         else if (gather8)
             hipLaunchKernelGGL((k_gather8<NW, 2>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
-                               qc, g.first, phase, ready, no_list, no_list);
+                               qc, g.first, phase, ready);
         else
             hipLaunchKernelGGL(k_gather<NW>, dim3((n + lanes - 1) / lanes), dim3(64), 0, g.stream, slots.p, g.end, cfg,
-                               bases(), q, qc, gather_rounds, lanes, g.first, phase, ready, no_list, no_list);
+                               bases(), q, qc, gather_rounds, lanes, g.first, phase, ready);
         if (timed_launch) {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
@@ -2182,8 +1659,7 @@ struct Engine {
     void launch_gather(bool to_queue) {
         hipLaunchKernelGGL(k_gather<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
                            to_queue ? queue.p : (LeafReq<NW>*)nullptr, to_queue ? queue_count.p : (uint32_t*)nullptr,
-                           gather_rounds, lanes, 0u, 0u, (uint32_t)SLOT_ACTIVE, (const uint32_t*)nullptr,
-                           (const uint32_t*)nullptr);
+                           gather_rounds, lanes, 0u, 0u, (uint32_t)SLOT_ACTIVE);
     }
     void launch_backup(bool from_queue) {
         hipLaunchKernelGGL(k_backup<NW>, dim3((S + lanes - 1) / lanes), dim3(64), 0, stream, slots.p, S, cfg, bases(),
@@ -2266,17 +1742,6 @@ struct Engine {
             }
         }
         gather_ev_used = 0;
-        if (hybrid && part_ctrl.p && getenv("AR_PART_DEBUG")) {
-            static int seen = 0;
-            if ((seen++ % 16) == 8) {
-                uint32_t h[8 + 2 * PART_BINS];
-                if (hipMemcpy(h, part_ctrl.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-                    fprintf(stderr, "[ar part] cut %u light %u heavy %u | rounds/8 histogram:", h[0], h[3], h[4]);
-                    for (int b = 0; b < PART_BINS; ++b) fprintf(stderr, " %u", h[8 + PART_BINS + b]);
-                    fprintf(stderr, "\n");
-                }
-            }
-        }
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
         for (int c = 0; c < POOL_CLASSES; ++c)
             if (pool.n[c] && h_counts.p[5 + c] < pool_low[c]) pool_low[c] = h_counts.p[5 + c];
@@ -2326,12 +1791,9 @@ struct Engine {
             r.slot = si.slot;
             r.cap = ncap;
             r.stats_off = (long long)(na - arena.p);
-            r.kids_off = r.stats_off + (long long)ncap * (long long)sizeof(NodeStats);
-            r.fwd_off = r.kids_off + (long long)ncap * (long long)sizeof(NodeKids);
+            r.fwd_off = r.stats_off + (long long)ncap * (long long)sizeof(NodeStats);
             HIP_TRY(hipMemcpyAsync(na, arena.p + si.stats_off, (size_t)si.hi * sizeof(NodeStats), hipMemcpyDeviceToDevice,
                                    stream));
-            HIP_TRY(hipMemcpyAsync(na + (size_t)ncap * sizeof(NodeStats), arena.p + si.kids_off,
-                                   (size_t)si.hi * sizeof(NodeKids), hipMemcpyDeviceToDevice, stream));
             reqs[i] = r;
         }
         if (n_stall == 0) return AR_OK;
@@ -2736,7 +2198,7 @@ struct SelfPlaySession : SessionBase {
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = eng.backup_lanes = (uint32_t)atoi(e);
         if (const char* e = getenv("AR_BACKUP_LANES"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.backup_lanes = (uint32_t)atoi(e);
-        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.gather4 = eng.hybrid = false;  // the round limit parks the walk: lane and pair kernels only
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = false;  // the round limit parks the walk: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();

@@ -94,7 +94,6 @@ struct OctShared {
 template <int NW>
 struct OctMem {
     NodeStats* stats;
-    NodeKids* kids;
     unsigned char* scratch;  // uniform base of all games' scratch
     const uint8_t* maze;     // uniform base of the maze pool
     uint32_t s_off;          // this game's scratch block
@@ -208,7 +207,7 @@ __device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Outcom
                 o.vtp[1] = v.y;
                 o.vtp[2] = v.z;
                 o.vtp[3] = v.w;
-                const uint4 k = *((const uint4*)&m.kids[L.node] + ol);
+                const uint4 k = *((const uint4*)&m.stats[L.node] + NODE_KID_GROUP + ol);
                 o.kid[0] = k.x;
                 o.kid[1] = k.y;
                 o.kid[2] = k.z;
@@ -275,8 +274,8 @@ __device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Outcom
                         uint4* S = (uint4*)&m.stats[nid];
                         S[ol] = g0;
                         if (ol < 5) S[8 + ol] = g1;
-                        if (ol < 7) ((uint4*)&m.kids[nid])[ol] = make_uint4(NIL, NIL, NIL, NIL);
-                        if (ol == 0) m.kids[o.node].c[idx] = nid;
+                        if (ol < 7) S[NODE_KID_GROUP + ol] = make_uint4(NIL, NIL, NIL, NIL);
+                        if (ol == 0) m.stats[o.node].c[idx] = nid;
                         o.node_count += 1;
                         o.d_new += 1;
                         emit_node = nid;
@@ -303,7 +302,7 @@ __device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Outcom
                 const NodeH1 b = N.h1;
                 const NodeH2 c = N.h2;
                 uint4 kin = make_uint4(NIL, NIL, NIL, NIL);
-                if (ol < 7) kin = *((const uint4*)&m.kids[rec] + ol);
+                if (ol < 7) kin = *((const uint4*)&N + NODE_KID_GROUP + ol);
                 if (a.visits == 0 || c.terminal != 0) {
                     // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
                     emit_node = rec;

@@ -3,11 +3,12 @@
 // crates/alpharat-sampling/src/selfplay.rs:515-598.
 //
 // Layout (one arena per game, all in HBM):
-//   NodeStats  256 B / node = sixteen 16-B groups: ten edge records {prior, q, visits, in_flight}
-//              ([player][outcome]) and three header groups. Every access below is a whole 16-B
-//              group, so a lane moves a node with dwordx4 loads/stores.
-//   NodeKids   128 B / node, a 25-slot child table indexed by (p1_outcome*5 + p2_outcome)
-//              (replaces the reference's linked list + find_child walk, tree.rs:52-63).
+//   NodeStats  320 B / node = twenty 16-B groups in five consecutive 64-byte lines: ten edge records
+//              {prior, q, visits, in_flight} ([player][outcome]), three header groups, and the 25-slot
+//              child table indexed by (p1_outcome*5 + p2_outcome) (replaces the reference's linked
+//              list + find_child walk, tree.rs:52-63). Every access below is a whole 16-B group, so a
+//              lane moves a node with dwordx4 loads/stores; a visit touches one contiguous record
+//              (rounds 1-2 kept the child table in a second array: six lines in two places per visit).
 // Node ids are arena indices; the live tree is [0, hi) and new nodes bump `hi`, so a parent's id is
 // always smaller than its children's. Moving the root (tree reuse, tree.rs:283-295) is an in-place
 // sliding compaction in id order done by a whole wavefront (advance_tree_*), which also yields the
@@ -49,17 +50,16 @@ struct alignas(16) NodeH2 {
     uint32_t meta;     // n_outcomes p1 | p2 << 8 | parent_outcome p1 << 16 | p2 << 24
     uint32_t terminal;
 };
-struct alignas(128) NodeStats {
+struct alignas(64) NodeStats {
     Edge e[2][5];
     NodeH0 h0;
     NodeH1 h1;
     NodeH2 h2;
-    uint32_t pad[12];
+    uint32_t c[25];  // child ids, NIL = no child yet
+    uint32_t pad[3];
 };
-struct alignas(128) NodeKids {
-    uint32_t c[25];
-    uint32_t pad[7];
-};
+static_assert(sizeof(NodeStats) == 320, "a node record is twenty 16-byte groups");
+enum { NODE_GROUPS = 20, NODE_KID_GROUP = 13 };  // groups per record; first group of the child table
 
 AR_HD uint32_t meta_n(uint32_t meta, int pl) { return (meta >> (8 * pl)) & 0xffu; }
 AR_HD uint32_t meta_po(uint32_t meta, int pl) { return (meta >> (16 + 8 * pl)) & 0xffu; }
@@ -125,7 +125,7 @@ struct alignas(128) Slot {
     uint32_t status;
     // arena: byte offsets from the arena base the kernels receive as an argument (so the compiler
     // can prove the accesses are to global memory)
-    long long stats_off, kids_off, fwd_off;
+    long long stats_off, fwd_off;
     uint32_t cap, hi, root, node_count;
     uint32_t pending_root;  // SLOT_ADVANCE: child to keep (NIL = fresh root)
     uint32_t need_nodes;    // capacity a stalled slot asks for
@@ -151,7 +151,6 @@ struct alignas(128) Slot {
 template <int NW>
 struct Mem {
     NodeStats* stats;
-    NodeKids* kids;
     uint32_t* fwd;          // [cap] new ids during the compaction
     ProcEntry* proc;        // [batch_size]
     CollEntry* coll;        // [coll_cap]
@@ -212,7 +211,7 @@ AR_HD void reduce_prior(uint32_t omap, const float* p5, float* out5) {
 }
 
 // shell node (tree.rs:107-148 extend_node + :199 edge rewards): all stores, no loads
-AR_HD void init_shell(NodeStats& nd, NodeKids& kd, uint32_t eff1, uint32_t eff2, uint16_t remaining,
+AR_HD void init_shell(NodeStats& nd, uint32_t eff1, uint32_t eff2, uint16_t remaining,
                       uint32_t parent, uint32_t o1, uint32_t o2, float r1, float r2) {
     Edge z;
     z.prior = 0.0f;
@@ -240,7 +239,8 @@ AR_HD void init_shell(NodeStats& nd, NodeKids& kd, uint32_t eff1, uint32_t eff2,
     h2.meta = n1 | (n2 << 8) | (o1 << 16) | (o2 << 24);
     h2.terminal = 0;
     nd.h2 = h2;
-    for (int i = 0; i < 25; ++i) kd.c[i] = NIL;
+    for (int i = 0; i < 25; ++i) nd.c[i] = NIL;
+    nd.pad[0] = nd.pad[1] = nd.pad[2] = NIL;
 }
 
 // tree.rs:351-365 alloc_root at arena index 0 (also MCTSTree::reinit, tree.rs:298-302)
@@ -248,7 +248,7 @@ template <int NW>
 AR_HD void make_root(Slot<NW>& s, const Mem<NW>& m) {
     const uint32_t e1 = eff_actions(m.cost, s.st.p1, s.st.m1), e2 = eff_actions(m.cost, s.st.p2, s.st.m2);
     NodeStats& nd = m.stats[0];
-    init_shell(nd, m.kids[0], e1, e2, s.st.remaining, NIL, 0, 0, 0.0f, 0.0f);
+    init_shell(nd, e1, e2, s.st.remaining, NIL, 0, 0, 0.0f, 0.0f);
     uint32_t om[2], nn[2];
     pack_outcomes(e1, om[0], nn[0]);
     pack_outcomes(e2, om[1], nn[1]);
@@ -615,7 +615,7 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
             g.omap1 = L.omap[1];
             for (int j = 0; j < 13; ++j) g.vtp[j] = L.vtp[j];
             g.work = L.saved;
-            const NodeKids& K = m.kids[L.node];
+            const NodeStats& K = m.stats[L.node];
             for (int j = 0; j < 25; ++j) g.kid[j] = K.c[j];
         } else {
             uint32_t rec = NIL;      // node whose record is inspected
@@ -663,9 +663,9 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                         s.error = 3;
                     } else {
                         const uint32_t nid = s.hi++;
-                        init_shell(m.stats[nid], m.kids[nid], eff_actions(m.cost, g.work.p1, g.work.m1),
+                        init_shell(m.stats[nid], eff_actions(m.cost, g.work.p1, g.work.m1),
                                    eff_actions(m.cost, g.work.p2, g.work.m2), g.work.remaining, g.node, o1, o2, r1, r2);
-                        m.kids[g.node].c[idx] = nid;
+                        m.stats[g.node].c[idx] = nid;
                         s.node_count += 1;
                         s.new_nodes += 1;
                         m.stats[nid].h0.nif = 1;  // try_start_score_update on a fresh node
@@ -693,9 +693,8 @@ AR_HD void gather_round(GatherLane<NW>& g, Slot<NW>& s, const Mem<NW>& m, const 
                 const NodeH1 b = N.h1;
                 const NodeH2 c = N.h2;
                 // its child table rides along in the same round trip (used if the node is expanded)
-                const NodeKids& K = m.kids[rec];
                 uint32_t kid_in[25];
-                for (int j = 0; j < 25; ++j) kid_in[j] = K.c[j];
+                for (int j = 0; j < 25; ++j) kid_in[j] = N.c[j];
                 if (a.visits == 0 || c.terminal != 0) {
                     // leaf or terminal (search.rs:591-636 for the root, :675-706 for a child)
                     AR_COUNT(131);
@@ -793,7 +792,6 @@ AR_HD bool gather_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, i
 // parks its state in the slot's scratch and resumes at the next call; only complete batches go on to
 // the evaluator and the backup. Per-game results do not depend on where the cuts fall.
 enum { GATHER_STALLED = 0, GATHER_COMPLETE = 1, GATHER_PENDING = 2 };
-enum { PAIR_PARK_BYTES = 768 };  // slot_layout.h: room for dev_gather2.h's PairParked without its State
 template <int NW>
 AR_HD int gather_machine_limited(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int eval_mode,
                                  uint32_t max_rounds) {
@@ -1245,7 +1243,7 @@ AR_HD void finish_move(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     // tree.rs:284-285: the child to keep, looked up before the position changes
     const NodeH2 c = m.stats[s.root].h2;
     const uint32_t ci = action_outcome(c.omap[0], (uint32_t)a1) * 5 + action_outcome(c.omap[1], (uint32_t)a2);
-    const uint32_t child = m.kids[s.root].c[ci];
+    const uint32_t child = m.stats[s.root].c[ci];
     float r1, r2;
     st_step(s.board, m.cost, s.st, (uint32_t)a1, (uint32_t)a2, r1, r2);
     if (st_over(s.board, s.st)) {
@@ -1288,12 +1286,10 @@ AR_HD void advance_tree_scalar(Slot<NW>& s, const Mem<NW>& m) {
         const uint32_t ni = m.fwd[i];
         if (ni == NIL) continue;
         NodeStats nd = m.stats[i];
-        NodeKids kd = m.kids[i];
         nd.h1.parent = i == keep_root ? NIL : m.fwd[nd.h1.parent];
         for (int c = 0; c < 25; ++c)
-            if (kd.c[c] != NIL) kd.c[c] = m.fwd[kd.c[c]];
+            if (nd.c[c] != NIL) nd.c[c] = m.fwd[nd.c[c]];
         m.stats[ni] = nd;
-        m.kids[ni] = kd;
     }
     s.root = 0;
     s.hi = cnt;

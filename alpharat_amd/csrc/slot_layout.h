@@ -36,10 +36,8 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     L.pos_off = off;
     off = align_up(off + sizeof(PosRec<NW>) * (max_turns > 0 ? max_turns : 1), 64);
     L.glane_off = off;
-    // (a parked gather: the lane kernel's GatherLane, or the pair kernel's PairParked -- dev_gather2.h: replicated walk
-    // state, two HalfAllocs, the current node's child table and allocated visits)
-    const size_t park_pair = PAIR_PARK_BYTES + sizeof(State<NW>);
-    off = align_up(off + (sizeof(GatherLane<NW>) > park_pair ? sizeof(GatherLane<NW>) : park_pair), 256);
+    // (a parked gather: the lane kernel's GatherLane)
+    off = align_up(off + sizeof(GatherLane<NW>), 256);
     L.total = off;
     return L;
 }
@@ -52,7 +50,6 @@ AR_HD Mem<NW> resolve_mem(const Slot<NW>& s, unsigned char* arena_base, unsigned
                           const SlotLayout& L, const uint8_t* maze_pool) {
     Mem<NW> m;
     m.stats = (NodeStats*)(arena_base + s.stats_off);
-    m.kids = (NodeKids*)(arena_base + s.kids_off);
     m.fwd = (uint32_t*)(arena_base + s.fwd_off);
     unsigned char* base = scratch_base + (size_t)slot_id * L.total;
     m.proc = (ProcEntry*)(base + L.proc_off);
@@ -80,7 +77,10 @@ inline uint32_t initial_arena_nodes(const SearchCfg& cfg) {
     uint32_t p = next_pow2(want);
     return p < 256 ? 256 : p;
 }
-// bytes of one arena of `cap` nodes: [stats | kids | fwd]
-AR_HD size_t arena_bytes(uint32_t cap) { return (size_t)cap * (sizeof(NodeStats) + sizeof(NodeKids) + sizeof(uint32_t)); }
+// bytes of one arena of `cap` nodes: [node records | fwd]
+// (rounded up to a whole number of 64-byte lines, so consecutive arenas keep the records' alignment)
+AR_HD size_t arena_bytes(uint32_t cap) {
+    return ((size_t)cap * (sizeof(NodeStats) + sizeof(uint32_t)) + 63) & ~(size_t)63;
+}
 
 }  // namespace ar

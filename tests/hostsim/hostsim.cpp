@@ -33,7 +33,7 @@ struct HsGame {
 struct HsRun {
     Slot<4> slot;
     std::vector<unsigned char> scratch;
-    std::vector<unsigned char> arena;  // [stats | kids | fwd]
+    std::vector<unsigned char> arena;  // [node records | fwd]
     std::vector<uint8_t> cost;
     SearchCfg cfg;
     SlotLayout L;
@@ -66,8 +66,7 @@ static SearchCfg to_cfg(const HsCfg* c, uint32_t n_sims, uint32_t batch) {
 static void set_arena(HsRun* r, uint32_t cap) {
     r->slot.cap = cap;
     r->slot.stats_off = 0;
-    r->slot.kids_off = (long long)((size_t)cap * sizeof(NodeStats));
-    r->slot.fwd_off = r->slot.kids_off + (long long)((size_t)cap * sizeof(NodeKids));
+    r->slot.fwd_off = (long long)((size_t)cap * sizeof(NodeStats));
 }
 
 // what the runtime does for a stalled slot: a doubled arena, live nodes copied across unchanged
@@ -75,10 +74,8 @@ static void grow(HsRun* r) {
     uint32_t ncap = r->slot.cap * 2;
     while (ncap < r->slot.need_nodes) ncap *= 2;
     std::vector<unsigned char> na(arena_bytes(ncap) + 256);
-    const uint32_t hi = r->slot.hi, ocap = r->slot.cap;
+    const uint32_t hi = r->slot.hi;
     std::memcpy(na.data(), r->arena.data(), (size_t)hi * sizeof(NodeStats));
-    std::memcpy(na.data() + (size_t)ncap * sizeof(NodeStats), r->arena.data() + (size_t)ocap * sizeof(NodeStats),
-                (size_t)hi * sizeof(NodeKids));
     r->arena.swap(na);
     set_arena(r, ncap);
     r->slot.status = SLOT_ACTIVE;
@@ -280,7 +277,7 @@ uint32_t hs_tree_dump(const void* p, uint32_t* out, uint32_t max_nodes) {
         }
         ++count;
         for (int i = 24; i >= 0; --i)
-            if (m.kids[it.id].c[i] != NIL) st.push_back({m.kids[it.id].c[i], it.depth + 1});
+            if (m.stats[it.id].c[i] != NIL) st.push_back({m.stats[it.id].c[i], it.depth + 1});
     }
     return count;
 }
