@@ -29,6 +29,7 @@
 #include "npz_writer.h"
 #include "slot_layout.h"
 #include "dev_gather8.h"
+#include "dev_gatherw.h"
 #include "dev_backup16.h"
 #include "zig_norm_tables.inc"
 
@@ -415,6 +416,142 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
     if (ol == 0) {
         if (stalled) S.need_nodes = S.hi + cfg.n_sims + 2 * cfg.batch_size;
         S.status = tag_status(status, phase);
+    }
+}
+
+
+// The gather as a work queue over tree levels (dev_gatherw.h): a wavefront serves G game contexts at once, every node
+// a pick reaches is an item in the wavefront's LDS ring, and each pass the 64 lanes take the next 64 items -- of
+// whichever games they are. The grid is persistent: a context whose game has finished its gather takes the next game of
+// the launch from a device-wide counter (`next_game`, zeroed before the launch), so the lanes stay busy until the
+// launch runs out of games. Leaves are left in the games' scratch (k_pack_leaves appends them to the evaluator queue).
+// Ring item: context (bits 0..6), BEGIN flag (bit 7: the context wants a game), visit slot, siblings behind it.
+template <int NW, int G>
+__global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B, uint32_t first,
+                                                uint32_t phase, uint32_t accept_ready, uint32_t* next_game) {
+    static_assert(G * GW_SLOTS <= GW_RING, "every entry of every context fits the ring");
+    __shared__ GwShared<NW, G> sh;
+    __shared__ GwOutcomeTable otab;
+    extern __shared__ uint32_t lds_maze[];  // the shared maze (B.maze_stage bytes), if the run has one
+    const uint32_t L = threadIdx.x;
+    GwMem<NW> m;
+    m.arena = B.arena;
+    m.scratch = B.scratch;
+    m.maze = B.maze;
+    if (B.maze_stage) {
+        for (uint32_t w = L; w < B.maze_stage / 4; w += 64) lds_maze[w] = ((const uint32_t*)B.maze)[w];
+        m.maze = (const uint8_t*)lds_maze;
+    }
+    m.slot_bytes = B.L.total;
+    m.proc_off = (uint32_t)B.L.proc_off;
+    m.coll_off = (uint32_t)B.L.coll_off;
+    m.leaf_off = (uint32_t)B.L.leaf_off;
+    m.coll_cap = B.L.coll_cap;
+    if (L < 17) gw_outcome_entry(L, otab.omap[L], otab.n[L]);
+    if (L == 0) sh.tail = G;
+    if (L < G) {
+        sh.game[L].slot = NIL;
+        sh.game[L].running = 0;
+        sh.ring[L] = (uint16_t)(L | 0x80u);  // every context starts by asking for a game
+    }
+    uint32_t head = 0;
+    for (uint32_t guard = 0; guard < (1u << 24); ++guard) {  // (the queue drains; the bound is a fuse)
+        __syncthreads();
+        const uint32_t n = *(volatile uint32_t*)&sh.tail - head;
+        if (n == 0) break;
+        uint32_t take = n < 64u ? n : 64u;
+        const uint32_t item = L < take ? (uint32_t)sh.ring[(head + L) & (GW_RING - 1)] : 0u;
+        {
+            // the children of one parent are taken in the same pass (they all read the parent's position first)
+            const unsigned long long split = __ballot(L < take && L + ((item >> 12) & 15u) >= 64u);
+            if (split) take = (uint32_t)__ffsll((long long)split) - 1u;
+        }
+        head += take;
+        const bool mine = L < take;
+        const bool begin = mine && (item & 0x80u);
+        const uint32_t g = item & 0x7fu;
+        GwLane<NW> ln;
+        ln.active = mine && !begin;
+        ln.g = g;
+        // ---- phase 1
+        uint32_t slot_i = NIL;
+        if (begin) slot_i = first + atomicAdd(next_game, 1u);
+        if (ln.active) gw_fetch(ln, item & 0xff7fu, sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
+        // ---- phase 2
+        bool started = false, retire = false;
+        if (begin) {
+            if (slot_i >= n_slots) {
+                retire = true;
+            } else {
+                Slot<NW>& S = slots[slot_i];
+                const uint32_t st = S.status;
+                const bool run = st == SLOT_ACTIVE || st == accept_ready;
+                if (run) {
+                    uint32_t status = SLOT_ACTIVE;
+                    if (S.batch_active == 0) {  // (a batch that still waits for its backup is left alone)
+                        GwGame<NW>& Gm = sh.game[g];
+                        gw_begin(Gm, S, slot_i, cfg);
+                        started = Gm.began != 0;
+                        if (Gm.stalled) {
+                            gw_end(Gm, S, cfg);
+                            status = SLOT_STALL;
+                        }
+                    }
+                    if (!started) S.status = tag_status(status, phase);
+                }
+            }
+        }
+        if (ln.active) gw_visit(ln, sh.game[g], m, cfg, &otab);
+        __syncthreads();
+        // ---- phase 3
+        bool finisher = false;
+        if (ln.active) finisher = gw_publish(ln, sh.game[g], sh.rec[g], sh.stub[g], sh.stub_node[g], sh.fin[g], sh.ring, &sh.tail);
+        __syncthreads();
+        // ---- phase 4: the end of a pick / the first pick of a new game / the next game for a context
+        if (finisher) gw_finish_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.fin[g], sh.ring, &sh.tail, g, m, cfg);
+        if (started) gw_next_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.ring, &sh.tail, g);
+        if (finisher || started) {
+            GwGame<NW>& Gm = sh.game[g];
+            if (!Gm.running) {  // the game's gather is complete: hand the slot back, ask for another game
+                Slot<NW>& S = slots[Gm.slot];
+                gw_end(Gm, S, cfg);
+                S.status = tag_status(SLOT_ACTIVE, phase);
+                Gm.slot = NIL;
+                sh.ring[atomicAdd(&sh.tail, 1u) & (GW_RING - 1)] = (uint16_t)(g | 0x80u);
+            }
+        } else if (begin && !retire) {
+            sh.ring[atomicAdd(&sh.tail, 1u) & (GW_RING - 1)] = (uint16_t)(g | 0x80u);  // not a game to walk: try the next one
+        }
+    }
+}
+
+// The evaluation requests of the games that have just gathered a batch, appended to the device-wide leaf queue
+// (replaces MuxBackend's request queue, mux.rs:170-289): one atomic per wavefront reserves the run, every lane copies its
+// game's leaves. Only the order of games in the queue depends on the scheduling.
+template <int NW>
+__global__ void __launch_bounds__(64) k_pack_leaves(Slot<NW>* slots, uint32_t n_slots, Bases B, uint32_t first, LeafReq<NW>* queue,
+                                                    uint32_t* queue_count) {
+    const uint32_t i = first + blockIdx.x * 64u + threadIdx.x;
+    uint32_t nn = 0;
+    if (i < n_slots && slots[i].status == SLOT_ACTIVE && slots[i].batch_active != 0) nn = slots[i].b_nn;
+    uint32_t incl = nn;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t base = 0;
+    if (threadIdx.x == 0 && total) base = atomicAdd(queue_count, total);
+    base = (uint32_t)__shfl((int)base, 0, 64) + incl - nn;
+    if (nn == 0) return;
+    slots[i].eval_base = base;
+    const State<NW>* leaves = (const State<NW>*)(B.scratch + (size_t)i * B.L.total + B.L.leaf_off);
+    for (uint32_t j = 0; j < nn; ++j) {
+        LeafReq<NW> r;
+        r.st = leaves[j];
+        r.slot = i;
+        r.pad = 0;
+        queue[base + j] = r;
     }
 }
 
@@ -1328,6 +1465,10 @@ struct Engine {
     bool use_queue() const { return net != nullptr || uniform_queue; }
     bool gather8 = false; // network path: the eight-lanes-per-game gather (k_gather8) instead of k_gather
     int gather8_wpe = 2;  // its register budget: 2 wavefronts per SIMD (no spills) or 4 (128 VGPRs, spills to scratch)
+    // network path: the gather as a work queue over tree levels (k_gatherw, dev_gatherw.h); a persistent grid of `gatherw_waves`
+    bool gatherw = false;
+    uint32_t gatherw_waves = 2048;
+    DevBuf<uint32_t> gw_next;  // per group: the next game of the launch
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
@@ -1411,6 +1552,18 @@ struct Engine {
         if (const char* e = getenv("AR_GATHER"))
             if (std::string(e).rfind("octet", 0) == 0)
                 gather8_wpe = std::string(e) == "octet4" ? 4 : std::string(e) == "octet3" ? 3 : std::string(e) == "octet2" ? 2 : gather8_wpe;
+        // the work-queue gather serves batches of up to GW_SLOTS descents; with uniform priors nearly every allocation step
+        // draws a tie break, which puts its items in sequence again: those runs keep the eight-lane kernel
+        gatherw = need_queue && net != nullptr && cfg.batch_size <= GW_SLOTS;
+        if (const char* e = getenv("AR_GATHER")) gatherw = std::string(e) == "wide" && need_queue && cfg.batch_size <= GW_SLOTS;
+        if (gatherw) {
+            int cus = 0;
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            gatherw_waves = (uint32_t)(cus > 0 ? cus : 256) * 8u;  // two wavefronts per SIMD (what the contexts' LDS allows)
+            if (const char* e = getenv("AR_GW_WAVES"))
+                if (atoi(e) > 0) gatherw_waves = (uint32_t)atoi(e);
+            HIP_TRY(gw_next.alloc(64));
+        }
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
@@ -1588,6 +1741,7 @@ struct Engine {
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
+        if (gatherw) HIP_TRY(hipMemsetAsync(gw_next.p + gi, 0, 4, g.stream));
         const bool timed_launch = true;  // every group's gather launch is timed on its own stream
         if (timed_launch) {
             while (gather_ev.size() < gather_ev_used + 2) {
@@ -1597,7 +1751,14 @@ struct Engine {
             }
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used], g.stream));
         }
-        if (gather8 && gather8_wpe == 3)
+        if (gatherw) {
+            // a persistent grid: at most gatherw_waves wavefronts, and at small sizes about four games per wavefront
+            constexpr int GWG = NW == 1 ? 16 : 8;
+            uint32_t waves = (n + 3) / 4;
+            if (waves > gatherw_waves) waves = gatherw_waves;
+            hipLaunchKernelGGL((k_gatherw<NW, GWG>), dim3(waves), dim3(64), (size_t)bases().maze_stage, g.stream, slots.p, g.end, cfg,
+                               bases(), g.first, phase, ready, gw_next.p + gi);
+        } else if (gather8 && gather8_wpe == 3)
             hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
                                qc, g.first, phase, ready);
         else if (gather8 && gather8_wpe == 4)
@@ -1613,6 +1774,8 @@ struct Engine {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
         }
+        if (gatherw)
+            hipLaunchKernelGGL(k_pack_leaves<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, bases(), g.first, q, qc);
         const uint32_t n_max = (uint32_t)((size_t)n * cfg.batch_size);
         if (cache_entries && net != nullptr) {
             LeafReq<NW>* mq = miss_queue.p + (size_t)g.first * cfg.batch_size;
@@ -2198,7 +2361,7 @@ struct SelfPlaySession : SessionBase {
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.lanes = eng.backup_lanes = (uint32_t)atoi(e);
         if (const char* e = getenv("AR_BACKUP_LANES"))
             if (atoi(e) >= 1 && atoi(e) <= 64) eng.backup_lanes = (uint32_t)atoi(e);
-        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = false;  // the round limit parks the walk: lane kernel only
+        if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.gatherw = false;  // the round limit parks the walk: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);
         t0 = std::chrono::steady_clock::now();

@@ -43,7 +43,7 @@ template <int NW>
 __device__ inline bool backup16_wants(const Slot<NW>& S, const Mem<NW>& m, const SearchCfg& cfg) {
     if (!(cfg.noise_epsilon > 0.0f)) return true;
     const ProcEntry pe = m.proc[0];
-    return !(S.n_proc >= 1 && pe.node == S.root && pe.kind == PROC_EVAL);
+    return !(S.n_proc >= 1 && pe.node == S.root && proc_kind(pe.kind) == PROC_EVAL);
 }
 
 template <int NW>
@@ -60,26 +60,12 @@ __device__ inline void backup16(bool active, Slot<NW>& S, const Mem<NW>& m, cons
         const uint32_t e = base + w;
         const bool mine = e < n_proc;
         // ---- 1. the path of entry e
-        uint32_t kind = PROC_TERMINAL, D = 0, leaf = NIL;
+        uint32_t kind = PROC_TERMINAL, D = 0, leaf = NIL, ev_idx = 0;
         if (mine) {
             const ProcEntry pe = m.proc[e];
-            kind = pe.kind;
+            kind = proc_kind(pe.kind);
             leaf = pe.node;
-        }
-        // evaluator outputs are stored in gather order: index = EVAL entries before e
-        uint32_t ev_idx = 0;
-        {
-            const unsigned long long evals = __ballot(mine && kind == PROC_EVAL);
-            const uint32_t g16 = (threadIdx.x & 48u);
-            const unsigned long long mine_mask = ((1ULL << w) - 1ULL) << g16;
-            ev_idx = (uint32_t)__popcll(evals & mine_mask);
-            // entries of earlier chunks
-            for (uint32_t b = 0; b < base; b += 16) {
-                const uint32_t ee = b + w;
-                const bool ev_e = active && ee < n_proc && m.proc[ee].kind == PROC_EVAL;
-                const unsigned long long pm = __ballot(ev_e);
-                ev_idx += (uint32_t)__popcll(pm & (0xFFFFULL << g16));
-            }
+            ev_idx = proc_eval_index(pe.kind);  // where the evaluator put this leaf's outputs
         }
         {
             uint32_t cur = leaf, po = 0;

@@ -77,8 +77,10 @@ enum { PROC_TERMINAL = 0, PROC_EVAL = 1 };
 
 struct ProcEntry {
     uint32_t node;
-    uint32_t kind;
+    uint32_t kind;  // PROC_TERMINAL, or PROC_EVAL | (index of the leaf's evaluation in this batch's requests) << 8
 };
+AR_HD uint32_t proc_kind(uint32_t k) { return k & 0xffu; }
+AR_HD uint32_t proc_eval_index(uint32_t k) { return k >> 8; }
 struct CollEntry {
     uint32_t node;
     uint32_t mv;
@@ -490,7 +492,7 @@ AR_HD void emit_proc(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int ev
     const uint32_t i = s.n_proc++;
     ProcEntry pe;
     pe.node = node;
-    pe.kind = kind;
+    pe.kind = kind == PROC_EVAL ? kind | (s.b_nn << 8) : kind;
     m.proc[i] = pe;
     if (kind == PROC_EVAL) {
         const uint32_t j = s.b_nn++;
@@ -942,8 +944,8 @@ AR_HD void backup_round(BackupLane& b, Slot<NW>& s, const Mem<NW>& m, const Sear
         const NodeH1 h = N.h1;
         const NodeH2 c = N.h2;
         float g1 = 0.0f, g2 = 0.0f;
-        if (pe.kind == PROC_EVAL) {
-            const EvalOut o = ev[b.j++];
+        if (proc_kind(pe.kind) == PROC_EVAL) {
+            const EvalOut o = ev[proc_eval_index(pe.kind)];
             float red1[5], red2[5];
             reduce_prior(c.omap[0], o.p1, red1);  // populate_node (tree.rs:156-173)
             reduce_prior(c.omap[1], o.p2, red2);

@@ -62,7 +62,7 @@ WORKLOADS = {
             "4096 sims (tuned constants, batch 16, noise 0.25), PyRatCNN c64 res,res,gpool(32) random weights"),
 }
 # sources whose change invalidates a committed PMC traffic measurement of the tree kernels
-TRAFFIC_SOURCES = ("dev_search.h", "dev_gather8.h", "dev_gather2.h", "dev_gather4.h", "dev_backup16.h", "dev_engine.h", "dev_rng.h", "slot_layout.h", "alpharat_hip.hip")
+TRAFFIC_SOURCES = ("dev_search.h", "dev_gatherw.h", "dev_gather8.h", "dev_backup16.h", "dev_engine.h", "dev_rng.h", "slot_layout.h", "alpharat_hip.hip")
 
 
 def kernel_source_hash() -> str:
@@ -317,8 +317,9 @@ def main() -> int:
     if has_net and stats.gather_secs > 0:
         launches = max(stats.gather_launches, 1)
         avg_launch_s = stats.gather_secs / launches
-        # the library's default gather is the eight-lanes-per-game kernel; AR_GATHER=lane / pair select the others
-        kernel = {"lane": "k_gather", "pair": "k_gather2", "quad": "k_gather4"}.get(os.environ.get("AR_GATHER", ""), "k_gather8")
+        # the library's default gather is the work-queue kernel; AR_GATHER=lane / octet* select the others
+        sel = os.environ.get("AR_GATHER", "")
+        kernel = "k_gather" if sel == "lane" else "k_gather8" if sel.startswith("octet") else "k_gatherw"
     else:  # SmartUniform: one fused step kernel, timed as a whole
         gather_bytes += (B_NODE_VISIT - B_SELECT_VISIT) * stats.backup_node_visits
         launches = max(stats.steps, 1)

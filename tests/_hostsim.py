@@ -79,7 +79,7 @@ def run(og, max_turns, ocfg, n_sims, batch, seed, single=False, eval_mode=0, v1=
     cfg = cfg_from_oracle(ocfg)
     h = L.hs_run(C.byref(g), C.byref(cfg), n_sims, batch, seed, int(single), eval_mode, v1, v2, arena_nodes)
     try:
-        hdr = np.zeros(12, dtype=np.uint64)
+        hdr = np.zeros(14, dtype=np.uint64)
         fs = np.zeros(2, dtype=np.float32)
         L.hs_header(h, _p(hdr), _p(fs))
         n = int(hdr[0])
@@ -101,9 +101,38 @@ def run(og, max_turns, ocfg, n_sims, batch, seed, single=False, eval_mode=0, v1=
             n=n, status=int(hdr[1]), error=int(hdr[2]), grows=int(hdr[3]), node_count=nodes,
             total_simulations=int(hdr[5]), total_nn_evals=int(hdr[6]), total_terminals=int(hdr[7]),
             total_collisions=int(hdr[8]), gather_node_visits=int(hdr[9]), backup_node_visits=int(hdr[10]),
-            new_nodes=int(hdr[11]), final_p1_score=float(fs[0]), final_p2_score=float(fs[1]),
+            new_nodes=int(hdr[11]), wide_passes=int(hdr[12]), wide_gathers=int(hdr[13]), final_p1_score=float(fs[0]), final_p2_score=float(fs[1]),
             ints=ints[:n], floats=fl[:n], masks=masks[:n], final=fin, final_mask=fmask, last=last, last_counts=cnt,
             dump=dump[: min(got, max(nodes, 1))], dump_count=got,
         )
     finally:
         L.hs_free(h)
+
+
+def hashed_eval(width):
+    """The CPU harness's stand-in network (hostsim.cpp hashed_eval) as an `evaluate` function for
+    _oracle.CallbackBackend: priors and values that are a fixed hash of the position."""
+    M = 0xFFFFFFFF
+
+    def evaluate(leaves):
+        n = len(leaves)
+        p = np.zeros((2, n, 5), dtype=np.float32)
+        v = np.zeros((2, n), dtype=np.float32)
+        for i, l in enumerate(leaves):
+            c1 = l["p1"][1] * width + l["p1"][0]
+            c2 = l["p2"][1] * width + l["p2"][0]
+            x = (c1 * 7919 + c2 * 104729 + l["turn"] * 1299709) & M
+            for c in np.flatnonzero(l["cheese"]):
+                x = (x + (int(c) + 1) * 15485863) & M
+            for pl in range(2):
+                w = [np.float32(1 + ((((x + a * 40503 + pl * 7) & M) * 2654435761 & M) >> 8) % 1000) for a in range(5)]
+                tot = np.float32(0.0)
+                for a in range(5):
+                    tot = np.float32(tot + w[a])
+                for a in range(5):
+                    p[pl, i, a] = np.float32(w[a] / tot)
+            v[0, i] = np.float32(((x * 2246822519 & M) >> 10) % 64) / np.float32(16.0)
+            v[1, i] = np.float32(((x * 3266489917 & M) >> 10) % 64) / np.float32(16.0)
+        return p[0], p[1], v[0], v[1]
+
+    return evaluate

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../alpharat_amd/csrc/slot_layout.h"
+#include "../../alpharat_amd/csrc/dev_gatherw.h"
 #include "../../alpharat_amd/csrc/zig_norm_tables.inc"
 
 using namespace ar;
@@ -38,6 +39,7 @@ struct HsRun {
     SearchCfg cfg;
     SlotLayout L;
     uint32_t grows = 0;
+    uint64_t wide_passes = 0, wide_gathers = 0;
     Mem<4> mem() { return resolve_mem<4>(slot, arena.data(), scratch.data(), 0, L, cost.data()); }
     const Mem<4> cmem() const {
         return resolve_mem<4>(slot, const_cast<unsigned char*>(arena.data()),
@@ -80,6 +82,100 @@ static void grow(HsRun* r) {
     set_arena(r, ncap);
     r->slot.status = SLOT_ACTIVE;
     r->grows += 1;
+}
+
+// The work-queue gather (dev_gatherw.h) run the way a wavefront runs it: every pass takes a run of queued items (never
+// splitting the children of one parent), then phase by phase, lane after lane. `sched` varies how many items a pass
+// takes (1 = as many as 64 lanes can; otherwise a seeded random cut), so the result is checked not to depend on it.
+static bool wide_gather(HsRun* r, uint64_t& sched) {
+    typedef GwShared<4, 1> Sh;
+    static thread_local Sh sh;
+    Slot<4>& s = r->slot;
+    GwMem<4> m;
+    m.arena = r->arena.data();
+    m.scratch = r->scratch.data();
+    m.maze = r->cost.data();
+    m.slot_bytes = r->L.total;
+    m.proc_off = (uint32_t)r->L.proc_off;
+    m.coll_off = (uint32_t)r->L.coll_off;
+    m.leaf_off = (uint32_t)r->L.leaf_off;
+    m.coll_cap = r->L.coll_cap;
+    GwGame<4>& G = sh.game[0];
+    gw_begin(G, s, 0, r->cfg);
+    sh.tail = 0;
+    uint32_t head = 0;
+    if (G.began) gw_next_pick(G, sh.rec[0], sh.stub[0], sh.ring, &sh.tail, 0);
+    GwLane<4> lanes[64];
+    bool finisher[64];
+    uint64_t passes = 0;
+    while (head != sh.tail) {
+        uint32_t n = sh.tail - head, take = n < 64 ? n : 64;
+        if (sched != 1) {
+            sched = sched * 6364136223846793005ULL + 1442695040888963407ULL;
+            take = 1 + (uint32_t)((sched >> 33) % take);
+        }
+        // whole sibling groups only
+        while (true) {
+            const uint32_t last = sh.ring[(head + take - 1) & (GW_RING - 1)];
+            const uint32_t rem = (last >> 12) & 15u;
+            if (rem == 0) break;
+            take += rem;
+        }
+        if (take > 64) {  // a group that does not fit behind the cut: stop in front of it
+            uint32_t t2 = 0;
+            while (true) {
+                const uint32_t it = sh.ring[(head + t2) & (GW_RING - 1)];
+                const uint32_t rem = (it >> 12) & 15u;
+                if (t2 + rem + 1 > 64) break;
+                t2 += rem + 1;
+            }
+            take = t2;
+        }
+        for (uint32_t l = 0; l < take; ++l) {
+            lanes[l].active = true;
+            gw_fetch(lanes[l], sh.ring[(head + l) & (GW_RING - 1)], sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
+        }
+        head += take;
+        for (uint32_t l = 0; l < take; ++l) gw_visit(lanes[l], sh.game[lanes[l].g], m, r->cfg, (const GwOutcomeTable*)nullptr);
+        for (uint32_t l = 0; l < take; ++l) {
+            const uint32_t g = lanes[l].g;
+            finisher[l] = gw_publish(lanes[l], sh.game[g], sh.rec[g], sh.stub[g], sh.stub_node[g], sh.fin[g], sh.ring, &sh.tail);
+        }
+        for (uint32_t l = 0; l < take; ++l)
+            if (finisher[l]) {
+                const uint32_t g = lanes[l].g;
+                gw_finish_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.fin[g], sh.ring, &sh.tail, g, m, r->cfg);
+            }
+        passes += 1;
+    }
+    r->wide_passes += passes;
+    r->wide_gathers += 1;
+    gw_end(G, s, r->cfg);
+    if (G.stalled) {
+        s.status = SLOT_STALL;
+        return false;
+    }
+    return true;
+}
+
+// A stand-in for a network in the CPU harness: priors and values that are a fixed hash of the position, so that (unlike
+// uniform priors) outcomes almost never tie -- the regime the network-driven self-play runs in. tests/_hostsim.py
+// (hashed_eval) states the same function for the oracle's callback backend.
+static void hashed_eval(const State<4>& lf, EvalOut& o) {
+    uint32_t x = (uint32_t)lf.p1 * 7919u + (uint32_t)lf.p2 * 104729u + (uint32_t)lf.turn * 1299709u;
+    for (int c = 0; c < 256; ++c)
+        if (st_has_cheese(lf, c)) x += (uint32_t)(c + 1) * 15485863u;
+    for (int pl = 0; pl < 2; ++pl) {
+        float w[5], tot = 0.0f;
+        for (uint32_t a = 0; a < 5; ++a) {
+            const uint32_t h = (x + a * 40503u + (uint32_t)pl * 7u) * 2654435761u;
+            w[a] = (float)(1u + ((h >> 8) % 1000u));
+            tot += w[a];
+        }
+        for (int a = 0; a < 5; ++a) (pl == 0 ? o.p1 : o.p2)[a] = w[a] / tot;
+    }
+    o.v1 = (float)((x * 2246822519u >> 10) % 64u) / 16.0f;
+    o.v2 = (float)((x * 3266489917u >> 10) % 64u) / 16.0f;
 }
 
 // eval_mode 0: SmartUniform inline; 1: leaves stored, harness evaluates (uniform priors + constant
@@ -125,6 +221,8 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
     start_game(s, r->mem(), r->cfg);
     const int mode = eval_mode == 0 ? EVAL_UNIFORM : EVAL_STORE;
     std::vector<EvalOut> ev(batch);
+    uint64_t wide_sched = (eval_mode == 5 || eval_mode == 7) ? (seed | 2) : 1;
+    const bool hashed = eval_mode >= 6;  // 6, 7: work-queue gather; 8: lane gather -- evaluations from hashed_eval
     while (s.status == SLOT_ACTIVE || s.status == SLOT_STALL || s.status == SLOT_ADVANCE) {
         if (s.status == SLOT_STALL) {
             grow(r);
@@ -139,7 +237,9 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
             fused_machine(s, m, r->cfg, &g_zig, 3);
             continue;
         }
-        if (eval_mode == 3) {  // the self-play kernel's gather: cut off every few rounds, parked, resumed
+        if (eval_mode == 4 || eval_mode == 5 || eval_mode == 6 || eval_mode == 7) {  // the work-queue gather (dev_gatherw.h); 5, 7: random cuts of the queue
+            if (!wide_gather(r, wide_sched)) continue;
+        } else if (eval_mode == 3) {  // the self-play kernel's gather: cut off every few rounds, parked, resumed
             const int got = gather_machine_limited(s, m, r->cfg, mode, 7);
             if (got != GATHER_COMPLETE) continue;
         } else if (!gather_machine(s, m, r->cfg, mode)) continue;
@@ -147,6 +247,10 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
         if (eval_mode != 0) {
             for (uint32_t j = 0; j < s.b_nn; ++j) {
                 const State<4>& lf = m.leaf_local[j];
+                if (hashed) {
+                    hashed_eval(lf, ev[j]);
+                    continue;
+                }
                 uniform_prior(eff_actions(m.cost, lf.p1, lf.m1), ev[j].p1);
                 uniform_prior(eff_actions(m.cost, lf.p2, lf.m2), ev[j].p2);
                 ev[j].v1 = v1;
@@ -161,7 +265,7 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
 void hs_free(void* p) { delete (HsRun*)p; }
 
 // header: [n_positions, status, error, grows, node_count, result-unused...]
-void hs_header(const void* p, uint64_t out[12], float fs[2]) {
+void hs_header(const void* p, uint64_t out[14], float fs[2]) {
     const HsRun* r = (const HsRun*)p;
     const Slot<4>& s = r->slot;
     out[0] = s.n_pos;
@@ -176,6 +280,8 @@ void hs_header(const void* p, uint64_t out[12], float fs[2]) {
     out[9] = s.nv_gather;
     out[10] = s.nv_backup;
     out[11] = s.new_nodes;
+    out[12] = r->wide_passes;
+    out[13] = r->wide_gathers;
     fs[0] = s.st.s1;
     fs[1] = s.st.s2;
 }

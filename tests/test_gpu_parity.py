@@ -310,7 +310,7 @@ def test_selfplay_generated_mazes_bit_exact(maze_type, w, h, cheese, turns, extr
     assert seen_wall and seen_mud
 
 
-@pytest.mark.parametrize("shape", ["octet3", "lane"])
+@pytest.mark.parametrize("shape", ["wide", "octet3", "lane"])
 def test_selfplay_over_64_cells_on_the_other_gather_shapes(shape, monkeypatch):
     """Boards above 64 cells use the four-word cheese masks (the NW = 4 kernel instances), per-game generated mazes
     keep the cost tables in global memory instead of LDS: the four-, two- and one-lane gathers on that path

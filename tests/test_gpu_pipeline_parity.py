@@ -109,7 +109,7 @@ def test_network_selfplay_records_bit_exact(name, blob, sims, search, n_games, n
         assert want["total_nn_evals"] > 0 and max(ev.backend.sizes) <= 16
 
 
-@pytest.mark.parametrize("shape", ["octet3", "lane"])
+@pytest.mark.parametrize("shape", ["wide", "octet3", "lane"])
 def test_network_selfplay_other_gather_shapes_bit_exact_vs_oracle(shape, monkeypatch):
     """The gather kernels with four, two and one lane per game (AR_GATHER; eight lanes is the default the cases above run
     on) against the oracle at record level: tuned constants + noise, 600 simulations, more games than slots. (That all
