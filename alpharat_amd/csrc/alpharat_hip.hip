@@ -422,15 +422,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
 // The gather as a work queue over tree levels (dev_gatherw.h): a wavefront serves G game contexts at once, every node
 // a pick reaches is an item in the wavefront's LDS ring, and each pass the 64 lanes take the next 64 items -- of
-// whichever games they are. The grid is persistent: a context whose game has finished its gather takes the next game of
-// the launch from a device-wide counter (`next_game`, zeroed before the launch), so the lanes stay busy until the
+// whichever games they are. The grid is persistent: context c of wavefront b walks the games first + (j * gridDim.x + b) * G
+// + c, j = 0, 1, ... one after the other (consecutive slots per wavefront and turn), so the lanes stay busy until the
 // launch runs out of games. Leaves are left in the games' scratch (k_pack_leaves appends them to the evaluator queue).
 // Ring item: context (bits 0..6), BEGIN flag (bit 7: the context wants a game), visit slot, siblings behind it.
-template <int NW, int G>
+template <int NW, int G, int R>
 __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready, uint32_t* next_game) {
-    static_assert(G * GW_SLOTS <= GW_RING, "every entry of every context fits the ring");
-    __shared__ GwShared<NW, G> sh;
+                                                uint32_t phase, uint32_t accept_ready, uint32_t pass_limit) {
+    static_assert((G & (G - 1)) == 0 && G <= 64, "the ring is a power of two; a context number fits a ring item");
+    static_assert(sizeof(GwRec<NW>) == (sizeof(State<NW>) + 16 + 7) / 8 * 8, "slot_layout.h sizes the spill area");
+    typedef GwShared<NW, G, R> Sh;
+    __shared__ Sh sh;
+    const uint32_t ring_mask = Sh::RING - 1;
     __shared__ GwOutcomeTable otab;
     extern __shared__ uint32_t lds_maze[];  // the shared maze (B.maze_stage bytes), if the run has one
     const uint32_t L = threadIdx.x;
@@ -446,21 +449,33 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
     m.proc_off = (uint32_t)B.L.proc_off;
     m.coll_off = (uint32_t)B.L.coll_off;
     m.leaf_off = (uint32_t)B.L.leaf_off;
+    m.spill_off = (uint32_t)B.L.levels_off;
     m.coll_cap = B.L.coll_cap;
     if (L < 17) gw_outcome_entry(L, otab.omap[L], otab.n[L]);
     if (L == 0) sh.tail = G;
-    if (L < G) {
-        sh.game[L].slot = NIL;
-        sh.game[L].running = 0;
-        sh.ring[L] = (uint16_t)(L | 0x80u);  // every context starts by asking for a game
+    for (uint32_t c = L; c < (uint32_t)G; c += 64) {
+        sh.game[c].slot = NIL;
+        sh.game[c].running = 0;
+        sh.game[c].next_game = 0;
+        for (int j = 0; j < R; ++j) sh.rec_owner[c][j] = 0;
+        sh.ring[c] = (uint16_t)(c | 0x80u);  // every context starts by asking for a game
     }
     uint32_t head = 0;
+#if defined(AR_STATS)
+    // per-wavefront counters (lane 0): passes, items, begins, pick ends, waits, interior, final; 100 MHz clocks of the four phases
+    unsigned long long gs_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_clk[5] = {0, 0, 0, 0, 0}, gs_hist[17] = {0}, gs_x[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long gs_t0 = wall_clock64();
+#define GW_STAT(...) __VA_ARGS__
+#else
+#define GW_STAT(...)
+#endif
     for (uint32_t guard = 0; guard < (1u << 24); ++guard) {  // (the queue drains; the bound is a fuse)
         __syncthreads();
         const uint32_t n = *(volatile uint32_t*)&sh.tail - head;
         if (n == 0) break;
+        GW_STAT(const unsigned long long gs_a = wall_clock64();)
         uint32_t take = n < 64u ? n : 64u;
-        const uint32_t item = L < take ? (uint32_t)sh.ring[(head + L) & (GW_RING - 1)] : 0u;
+        const uint32_t item = L < take ? (uint32_t)sh.ring[(head + L) & ring_mask] : 0u;
         {
             // the children of one parent are taken in the same pass (they all read the parent's position first)
             const unsigned long long split = __ballot(L < take && L + ((item >> 12) & 15u) >= 64u);
@@ -469,15 +484,21 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
         head += take;
         const bool mine = L < take;
         const bool begin = mine && (item & 0x80u);
+        GW_STAT(gs_cnt[0] += 1; gs_cnt[1] += take; gs_cnt[2] += (unsigned long long)__popcll(__ballot(begin)); gs_hist[take / 4] += 1;)
         const uint32_t g = item & 0x7fu;
         GwLane<NW> ln;
         ln.active = mine && !begin;
         ln.g = g;
         // ---- phase 1
         uint32_t slot_i = NIL;
-        if (begin) slot_i = first + atomicAdd(next_game, 1u);
-        if (ln.active) gw_fetch(ln, item & 0xff7fu, sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
+        if (begin && guard < pass_limit) {  // (past the limit no game is begun: its turn comes with the next launch)
+            const uint32_t turn = sh.game[g].next_game;
+            sh.game[g].next_game = turn + 1u;
+            slot_i = first + (turn * gridDim.x + blockIdx.x) * (uint32_t)G + g;
+        }
+        if (ln.active) gw_fetch<NW, R>(ln, item, sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
         // ---- phase 2
+        GW_STAT(const unsigned long long gs_b = wall_clock64();)
         bool started = false, retire = false;
         if (begin) {
             if (slot_i >= n_slots) {
@@ -492,6 +513,7 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
                         GwGame<NW>& Gm = sh.game[g];
                         gw_begin(Gm, S, slot_i, cfg);
                         started = Gm.began != 0;
+                        GW_STAT(Gm.dbg_start = guard;)
                         if (Gm.stalled) {
                             gw_end(Gm, S, cfg);
                             status = SLOT_STALL;
@@ -501,28 +523,65 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
                 }
             }
         }
-        if (ln.active) gw_visit(ln, sh.game[g], m, cfg, &otab);
+        if (ln.active) gw_visit(ln, sh.game[g], sh.rec_owner[g], m, cfg, &otab);
         __syncthreads();
+        GW_STAT(const unsigned long long gs_c = wall_clock64();
+                gs_cnt[4] += (unsigned long long)__popcll(__ballot(ln.active && ln.wait));
+                gs_cnt[5] += (unsigned long long)__popcll(__ballot(ln.active && ln.interior));
+                gs_cnt[6] += (unsigned long long)__popcll(__ballot(ln.active && ln.is_final));
+                {
+                    // the slowest lane of the pass: allocation steps; clocks from the start of the phase to record arrival /
+                    // set-up / end of allocation (interior entries only)
+                    const bool in = ln.active && ln.interior;
+                    uint32_t st = in ? ln.dbg_steps : 0u, t0 = in ? (uint32_t)(ln.dbg_t[0] - gs_b) : 0u,
+                             t1 = in ? (uint32_t)(ln.dbg_t[1] - gs_b) : 0u, t2 = in ? (uint32_t)(ln.dbg_t[2] - gs_b) : 0u;
+                    uint32_t ssum = st;
+                    for (int off = 32; off > 0; off >>= 1) {
+                        st = max(st, (uint32_t)__shfl_xor((int)st, off, 64));
+                        ssum += (uint32_t)__shfl_xor((int)ssum, off, 64);
+                        t0 = max(t0, (uint32_t)__shfl_xor((int)t0, off, 64));
+                        t1 = max(t1, (uint32_t)__shfl_xor((int)t1, off, 64));
+                        t2 = max(t2, (uint32_t)__shfl_xor((int)t2, off, 64));
+                    }
+                    gs_x[0] += st; gs_x[1] += ssum; gs_x[2] += t0; gs_x[3] += t1; gs_x[4] += t2;
+                    gs_x[5] += (unsigned long long)__popcll(__ballot(ln.active && ln.from_pick));
+                })
         // ---- phase 3
         bool finisher = false;
-        if (ln.active) finisher = gw_publish(ln, sh.game[g], sh.rec[g], sh.stub[g], sh.stub_node[g], sh.fin[g], sh.ring, &sh.tail);
+        if (ln.active)
+            finisher = gw_publish<NW, R>(ln, sh.game[g], sh.rec[g], sh.rec_owner[g], m.spill(sh.game[g]), sh.stub[g], sh.stub_node[g],
+                                         sh.ring, ring_mask, &sh.tail);
         __syncthreads();
+        GW_STAT(const unsigned long long gs_d = wall_clock64(); gs_cnt[3] += (unsigned long long)__popcll(__ballot(finisher));)
         // ---- phase 4: the end of a pick / the first pick of a new game / the next game for a context
-        if (finisher) gw_finish_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.fin[g], sh.ring, &sh.tail, g, m, cfg);
-        if (started) gw_next_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.ring, &sh.tail, g);
+        if (finisher) gw_finish_pick(sh.game[g], sh.stub[g], sh.ring, ring_mask, &sh.tail, g, guard + 1u < pass_limit);
+        if (started) gw_next_pick(sh.game[g], sh.stub[g], sh.ring, ring_mask, &sh.tail, g);
         if (finisher || started) {
             GwGame<NW>& Gm = sh.game[g];
-            if (!Gm.running) {  // the game's gather is complete: hand the slot back, ask for another game
+            if (!Gm.running) {  // the game's gather is complete (or parked): hand the slot back, ask for another game
+                GW_STAT(atomicAdd(&g_gather_clk[64 + min((guard - Gm.dbg_start) / 8u, 47u)], 1ULL);)
                 Slot<NW>& S = slots[Gm.slot];
                 gw_end(Gm, S, cfg);
                 S.status = tag_status(SLOT_ACTIVE, phase);
                 Gm.slot = NIL;
-                sh.ring[atomicAdd(&sh.tail, 1u) & (GW_RING - 1)] = (uint16_t)(g | 0x80u);
+                sh.ring[atomicAdd(&sh.tail, 1u) & ring_mask] = (uint16_t)(g | 0x80u);
             }
         } else if (begin && !retire) {
-            sh.ring[atomicAdd(&sh.tail, 1u) & (GW_RING - 1)] = (uint16_t)(g | 0x80u);  // not a game to walk: try the next one
+            sh.ring[atomicAdd(&sh.tail, 1u) & ring_mask] = (uint16_t)(g | 0x80u);  // not a game to walk: try the next one
         }
+        GW_STAT(const unsigned long long gs_e = wall_clock64(); gs_clk[0] += gs_b - gs_a; gs_clk[1] += gs_c - gs_b;
+                gs_clk[2] += gs_d - gs_c; gs_clk[3] += gs_e - gs_d;)
     }
+#if defined(AR_STATS)
+    if (L == 0) {
+        gs_clk[4] = wall_clock64() - gs_t0;
+        atomicAdd(&g_gather_clk[0], 1ULL);
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_gather_clk[1 + k], gs_cnt[k]);
+        for (int k = 0; k < 5; ++k) atomicAdd(&g_gather_clk[8 + k], gs_clk[k]);
+        for (int k = 0; k < 17; ++k) atomicAdd(&g_gather_clk[16 + k], gs_hist[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_gather_clk[40 + k], gs_x[k]);
+    }
+#endif
 }
 
 // The evaluation requests of the games that have just gathered a batch, appended to the device-wide leaf queue
@@ -767,7 +826,8 @@ __global__ void k_cancel(Slot<NW>* slots, uint32_t n_slots, Bases B) {
     if (i >= n_slots) return;
     Slot<NW> s = slots[i];
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, i, B.L, B.maze);
-    if (s.batch_active) cancel_batch(s, m);
+    if (s.batch_active || s.gather_pending) cancel_batch(s, m);  // (a parked gather holds claims and virtual losses too)
+    s.gather_pending = 0;
     if (s.status == SLOT_ACTIVE) s.status = SLOT_FAILED;
     slots[i] = s;
 }
@@ -1408,6 +1468,22 @@ static int default_gather8_wpe(uint32_t resident_games) { return resident_games 
 // 7x7 / 1897 sims at 65536 games: 1180 M vs 1251 M): few games want k_gather8's wavefront count, many the fused kernel
 static bool default_uniform_queue(uint32_t resident_games) { return resident_games <= 16384u; }
 
+#if defined(AR_STATS)
+static void* g_dbg_slots;
+static uint32_t g_dbg_S, g_dbg_nw;
+template <int NW>
+__global__ void k_dbg_tree_hist(const Slot<NW>* slots, uint32_t n, unsigned long long* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Slot<NW>& s = slots[i];
+    if (s.status == SLOT_EMPTY || s.status == SLOT_DONE) return;
+    atomicAdd(&out[min(s.hi / 512u, 63u)], 1ULL);
+    atomicAdd(&out[64 + min(s.cap / 512u, 63u)], 1ULL);
+    atomicAdd(&out[128], (unsigned long long)s.hi);
+    atomicAdd(&out[129], (unsigned long long)s.cap);
+    atomicAdd(&out[130], 1ULL);
+}
+#endif
 template <int NW>
 struct Engine {
     int dev = 0;
@@ -1468,7 +1544,7 @@ struct Engine {
     // network path: the gather as a work queue over tree levels (k_gatherw, dev_gatherw.h); a persistent grid of `gatherw_waves`
     bool gatherw = false;
     uint32_t gatherw_waves = 2048;
-    DevBuf<uint32_t> gw_next;  // per group: the next game of the launch
+    uint32_t gatherw_passes = 0xFFFFFFFFu;  // passes one launch may run; gathers that are not complete then are parked between two picks
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
     DevBuf<uint32_t> pool_ids;
@@ -1559,16 +1635,22 @@ struct Engine {
         if (gatherw) {
             int cus = 0;
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            gatherw_waves = (uint32_t)(cus > 0 ? cus : 256) * 8u;  // two wavefronts per SIMD (what the contexts' LDS allows)
+            gatherw_waves = (uint32_t)(cus > 0 ? cus : 256) * 8u;  // two wavefronts per SIMD, 32 (16 on boards above 64 cells) games each
             if (const char* e = getenv("AR_GW_WAVES"))
                 if (atoi(e) > 0) gatherw_waves = (uint32_t)atoi(e);
-            HIP_TRY(gw_next.alloc(64));
+            if (const char* e = getenv("AR_GW_PASSES"))
+                if (atoi(e) > 0) gatherw_passes = (uint32_t)atoi(e);
         }
         cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
         HIP_TRY(slots.alloc(S));
         HIP_TRY(hipMemsetAsync(slots.p, 0, sizeof(Slot<NW>) * S, stream));
+#if defined(AR_STATS)
+        g_dbg_slots = slots.p;
+        g_dbg_S = S;
+        g_dbg_nw = NW;
+#endif
         HIP_TRY(scratch.alloc((size_t)S * L.total));
         if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = false;  // k_gather8 addresses scratch with 32-bit offsets
         // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
@@ -1741,7 +1823,6 @@ struct Engine {
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
-        if (gatherw) HIP_TRY(hipMemsetAsync(gw_next.p + gi, 0, 4, g.stream));
         const bool timed_launch = true;  // every group's gather launch is timed on its own stream
         if (timed_launch) {
             while (gather_ev.size() < gather_ev_used + 2) {
@@ -1753,11 +1834,11 @@ struct Engine {
         }
         if (gatherw) {
             // a persistent grid: at most gatherw_waves wavefronts, and at small sizes about four games per wavefront
-            constexpr int GWG = NW == 1 ? 16 : 8;
+            constexpr int GWG = NW == 1 ? 32 : 16;
             uint32_t waves = (n + 3) / 4;
             if (waves > gatherw_waves) waves = gatherw_waves;
-            hipLaunchKernelGGL((k_gatherw<NW, GWG>), dim3(waves), dim3(64), (size_t)bases().maze_stage, g.stream, slots.p, g.end, cfg,
-                               bases(), g.first, phase, ready, gw_next.p + gi);
+            hipLaunchKernelGGL((k_gatherw<NW, GWG, 4>), dim3(waves), dim3(64), (size_t)bases().maze_stage, g.stream, slots.p, g.end, cfg,
+                               bases(), g.first, phase, ready, gatherw_passes);
         } else if (gather8 && gather8_wpe == 3)
             hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
                                qc, g.first, phase, ready);
@@ -2801,6 +2882,20 @@ int ar_generate_cheese(uint8_t width, uint8_t height, uint8_t p1_cell, uint8_t p
 }
 
 #if defined(AR_STATS)
+// sizes of the resident trees: [0..64) games by live-tree top (hi) / 512, [64..128) by arena capacity / 512,
+// [128] sum of hi, [129] sum of cap, [130] games
+int ar_debug_tree_hist(unsigned long long* out131) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (!g_dbg_slots) return fail(AR_E_INVALID, "no session");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 131 * 8));
+    HIP_TRY(hipMemset(d, 0, 131 * 8));
+    if (g_dbg_nw == 1) hipLaunchKernelGGL(k_dbg_tree_hist<1>, dim3((g_dbg_S + 255) / 256), dim3(256), 0, 0, (const Slot<1>*)g_dbg_slots, g_dbg_S, d);
+    else hipLaunchKernelGGL(k_dbg_tree_hist<4>, dim3((g_dbg_S + 255) / 256), dim3(256), 0, 0, (const Slot<4>*)g_dbg_slots, g_dbg_S, d);
+    HIP_TRY(hipMemcpy(out131, d, 131 * 8, hipMemcpyDeviceToHost));
+    hipFree(d);
+    return AR_OK;
+}
 int ar_debug_round_stats(unsigned long long* out32) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(ar::g_round_stats), sizeof(unsigned long long) * 32));

@@ -61,11 +61,27 @@ __device__ inline void backup16(bool active, Slot<NW>& S, const Mem<NW>& m, cons
         const bool mine = e < n_proc;
         // ---- 1. the path of entry e
         uint32_t kind = PROC_TERMINAL, D = 0, leaf = NIL, ev_idx = 0;
-        if (mine) {
-            const ProcEntry pe = m.proc[e];
-            kind = proc_kind(pe.kind);
-            leaf = pe.node;
-            ev_idx = proc_eval_index(pe.kind);  // where the evaluator put this leaf's outputs
+        {
+            // lane w takes the w-th entry in backup order: rank by key among the chunk's entries (a chunk of the
+            // depth-first gathers' entries is in order already; the work-queue gather writes at most 16, in arrival order)
+            ProcEntry pe;
+            pe.node = NIL;
+            pe.kind = 0xFFFF0000u;
+            if (mine) pe = m.proc[e];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t kj = grp_pick(pe.kind, j) >> 16;
+                rank += (kj < (pe.kind >> 16) || (kj == (pe.kind >> 16) && j < w)) ? 1u : 0u;
+            }
+            uint32_t src = 0;
+            for (uint32_t j = 0; j < 16; ++j) src = grp_pick(rank, j) == w ? j : src;
+            pe.node = grp_pick(pe.node, src);
+            pe.kind = grp_pick(pe.kind, src);
+            if (mine) {  // (entries without a batch entry sort last: lanes >= n_proc - base get those)
+                kind = proc_kind(pe.kind);
+                leaf = pe.node;
+                ev_idx = proc_eval_index(pe.kind);  // where the evaluator put this leaf's outputs
+            }
         }
         {
             uint32_t cur = leaf, po = 0;

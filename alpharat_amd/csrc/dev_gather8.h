@@ -402,7 +402,7 @@ __device__ inline void gather8_round(Oct<NW>& o, OctShared<NW>& sh, const Outcom
                     if (ol == 0) {
                         ProcEntry pe;
                         pe.node = emit_node;
-                        pe.kind = emit_kind == PROC_EVAL ? emit_kind | (o.b_nn << 8) : emit_kind;
+                        pe.kind = (emit_kind == PROC_EVAL ? emit_kind | (o.b_nn << 8) : emit_kind) | (i << 16);
                         m.proc()[i] = pe;
                     }
                     if (emit_kind == PROC_EVAL) {

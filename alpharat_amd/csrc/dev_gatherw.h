@@ -13,8 +13,9 @@
 // So a pick is run level by level instead: all nodes of a level at once, ~12 dependent trips per pick instead of ~80.
 //   * The `budget` visits of a pick are numbered 0..budget-1 in depth-first order; a node that routes k visits owns k
 //     consecutive numbers ("visit slots") starting at its slot t, and its children, in child-slot order, take
-//     t, t + k_0, t + k_0 + k_1, ... So an entry's slot is its position in the depth-first order, nothing ever moves,
-//     and (a) is a scan over the slots when the pick is complete (gw_finish_pick).
+//     t, t + k_0, t + k_0 + k_1, ... So an entry's slot is its position in the depth-first order and nothing ever moves.
+//     For (a) a batch entry is written the moment its leaf is reached, in arrival order, with the key (pick number,
+//     slot); the backup takes the entries in key order (proc_sort / backup16).
 //   * (b): an allocation step that has to draw may only do so when every earlier slot is final (leaf reached), i.e.
 //     when everything the depth-first walk would have done before it is done. Otherwise the entry is put back in the
 //     queue untouched (nothing of an entry is written before its allocation is complete) and runs again later. With
@@ -33,11 +34,13 @@
 
 namespace ar {
 
-enum { GW_SLOTS = 16, GW_RING = 256 };  // visit slots per pick (= largest batch size served); ring entries (>= games x slots)
+enum { GW_SLOTS = 16 };  // visit slots per pick (= largest batch size served)
+enum { GW_SPILL = 7 };   // record reference of a stub: 0..R-1 = one of the game's records in LDS, GW_SPILL = the game's scratch in global memory
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GW_ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define GW_ATOMIC_OR(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define GW_ATOMIC_CAS(p, expect, v) atomicCAS((p), (expect), (v))
 #else
 AR_HD uint32_t gw_host_add(uint32_t* p, uint32_t v) {
     const uint32_t o = *p;
@@ -50,7 +53,13 @@ AR_HD uint32_t gw_host_or(uint32_t* p, uint32_t v) {
     return o;
 }
 #define GW_ATOMIC_ADD(p, v) gw_host_add((p), (v))
+AR_HD uint32_t gw_host_cas(uint32_t* p, uint32_t expect, uint32_t v) {
+    const uint32_t o = *p;
+    if (o == expect) *p = v;
+    return o;
+}
 #define GW_ATOMIC_OR(p, v) gw_host_or((p), (v))
+#define GW_ATOMIC_CAS(p, expect, v) gw_host_cas((p), (expect), (v))
 #endif
 
 struct alignas(16) GwU4 {
@@ -91,12 +100,6 @@ struct alignas(8) GwRec {
     uint32_t pad;
 };
 
-// a finished entry of the running pick (one per leading slot)
-struct GwFin {
-    uint32_t node;
-    uint32_t info;  // bit 31 valid | kind (PROC_*, PROC_NONE) | collision multivisits << 8 | evaluation index << 16
-};
-
 // one game as the wavefront sees it
 template <int NW>
 struct alignas(8) GwGame {
@@ -105,33 +108,44 @@ struct alignas(8) GwGame {
     Board board;
     long long stats_off;  // arena of the game, relative to the arena base
     uint32_t slot;        // slot index (NIL: no game in this context)
-    uint32_t root, hi, cap, node_count;
-    uint32_t n_proc, n_coll, b_nn, b_term, b_coll;
-    int32_t left;  // collision budget left (search.rs:970)
-    uint32_t batch, budget, pick_mv;
+    uint32_t root, cap;
+    // (updated with LDS atomics by the lanes that work for the game)
+    uint32_t hi, node_count, b_nn, d_new, d_visits, n_proc, n_coll, b_term, pick_mv;
     uint32_t final_mask;  // visit slots of the running pick that are final
-    uint32_t lead_mask;   // slots that hold a GwFin
-    uint32_t error, d_new, d_visits;
-    uint32_t running;     // 1: gather in progress
-    uint32_t stalled, began;
-    uint32_t eval_base;
+    uint32_t b_coll;
+    uint32_t next_game;   // (kernel) how many games this context has taken
+    int32_t left;  // collision budget left (search.rs:970)
+    uint8_t batch, budget, pick, error;  // pick: number of the running pick_nodes_to_extend call
+    uint8_t running;  // 1: gather in progress
+    uint8_t stalled, began;
+    uint8_t parked;   // 1: the launch's pass limit was reached between two picks: the gather goes on in the next launch
+#if defined(AR_STATS)
+    uint32_t dbg_start;  // pass of the wavefront in which the game began
+#endif
 };
 
-template <int NW, int G>
+// Everything a wavefront keeps about its G games. A parent's position record is needed from the pass that publishes its
+// children to the pass that takes them (the next one, as a rule); a game rarely has more than two or three such records
+// alive, so it owns R of them in LDS and a parent that finds them all taken puts its record in the game's scratch in
+// global memory instead (the slot's idle level-stack area; the children then read it from there).
+template <int NW, int G, int R>
 struct GwShared {
+    enum { RING = G * GW_SLOTS };  // every entry of every game fits (G a power of two)
     GwGame<NW> game[G];
-    GwRec<NW> rec[G][GW_SLOTS];
+    GwRec<NW> rec[G][R];
+    uint32_t rec_owner[G][R];         // 0: free; else slot + 1 of the entry whose record it is
     uint32_t stub[G][GW_SLOTS];
     uint32_t stub_node[G][GW_SLOTS];  // CHILD stubs: the child's node id (NIL: to be created), set by the parent
-    GwFin fin[G][GW_SLOTS];
-    uint16_t ring[GW_RING];
+    uint16_t ring[RING];
     uint32_t tail;
 };
 
-// stub of a queued entry: bit 0 child (position = parent's + one move), bit 1 first level of a pick, idx, visits, parent's slot
-AR_HD uint32_t gw_stub(bool child, bool from_pick, uint32_t idx, uint32_t k, uint32_t pslot) {
-    return (child ? 1u : 0u) | (from_pick ? 2u : 0u) | (idx << 2) | (k << 7) | (pslot << 12);
+// stub of a queued entry: bit 0 child (position = parent's + one move), bit 1 first level of a pick, idx, visits, where
+// the record is (its own for a re-queued entry, the parent's for a child): reference (3 bits) and slot of its owner
+AR_HD uint32_t gw_stub(bool child, bool from_pick, uint32_t idx, uint32_t k, uint32_t recref, uint32_t rslot) {
+    return (child ? 1u : 0u) | (from_pick ? 2u : 0u) | (idx << 2) | (k << 7) | (recref << 12) | (rslot << 15);
 }
+// ring item: game context (bits 0..6; bit 7 is the kernel's "context wants a game" flag), visit slot, siblings behind it
 AR_HD uint16_t gw_item(uint32_t g, uint32_t t, uint32_t rem) { return (uint16_t)(g | (t << 8) | (rem << 12)); }
 
 // what a lane carries through the phases of one pass (registers on the device)
@@ -140,6 +154,7 @@ struct GwLane {
     bool active;
     uint32_t g, t, k, idx;
     bool child, from_pick;
+    uint32_t free_ref;  // record in LDS this entry releases (it was the last to read it), or GW_SPILL
     State<NW> pos;
     uint32_t node, parent;
     float r1, r2;
@@ -149,6 +164,10 @@ struct GwLane {
     uint32_t omap0, omap1, mask;
     uint32_t vtp[5];  // visits allocated to child slot (o1, o2): field o2 (6 bits) of word o1
     uint32_t kid[25];  // the node's child table (it arrives with the record: the children need no trip of their own for their ids)
+#if defined(AR_STATS)
+    uint32_t dbg_steps;               // allocation steps of this entry
+    unsigned long long dbg_t[3];      // 100 MHz clock: record arrived, set-up done, allocation done
+#endif
 };
 
 // Element `i` of a small array that lives in registers, as an OR over masked elements: a chain of `i == 0 ? a[0] : ...`
@@ -297,18 +316,19 @@ struct GwMem {
     unsigned char* scratch;
     const uint8_t* maze;  // cost tables (LDS copy when the run has one shared maze)
     size_t slot_bytes;
-    uint32_t proc_off, coll_off, leaf_off, coll_cap;
+    uint32_t proc_off, coll_off, leaf_off, spill_off, coll_cap;
     AR_HD NodeStats* stats(const GwGame<NW>& G) const { return (NodeStats*)(arena + G.stats_off); }
     AR_HD const uint8_t* cost(const GwGame<NW>& G) const { return maze + G.board.maze_off; }
     AR_HD ProcEntry* proc(const GwGame<NW>& G) const { return (ProcEntry*)(scratch + (size_t)G.slot * slot_bytes + proc_off); }
     AR_HD CollEntry* coll(const GwGame<NW>& G) const { return (CollEntry*)(scratch + (size_t)G.slot * slot_bytes + coll_off); }
     AR_HD State<NW>* leaves(const GwGame<NW>& G) const { return (State<NW>*)(scratch + (size_t)G.slot * slot_bytes + leaf_off); }
+    AR_HD GwRec<NW>* spill(const GwGame<NW>& G) const { return (GwRec<NW>*)(scratch + (size_t)G.slot * slot_bytes + spill_off); }
 };
 
 // Starts the next pick_nodes_to_extend call of a game (search.rs:981-999), or ends its gather. Returns true when an
-// item for the root was queued.
+// item for the root was queued (the root's position is the game's: it needs no record).
 template <int NW>
-AR_HD bool gw_next_pick(GwGame<NW>& G, GwRec<NW>* rec, uint32_t* stub, uint16_t* ring, uint32_t* tail, uint32_t g) {
+AR_HD bool gw_next_pick(GwGame<NW>& G, uint32_t* stub, uint16_t* ring, uint32_t ring_mask, uint32_t* tail, uint32_t g) {
     if (!(G.n_proc < G.batch && G.left > 0)) {
         G.running = 0;
         return false;
@@ -316,50 +336,57 @@ AR_HD bool gw_next_pick(GwGame<NW>& G, GwRec<NW>* rec, uint32_t* stub, uint16_t*
     uint32_t budget = (uint32_t)G.left;
     if (G.batch - G.n_proc < budget) budget = G.batch - G.n_proc;
     G.budget = budget;
+    G.pick += 1;
     G.pick_mv = 0;
     G.final_mask = 0;
-    G.lead_mask = 0;
-    GwRec<NW> r;
-    r.pos = G.root_st;
-    r.omap0 = r.omap1 = 0;
-    r.node = G.root;
-    r.pad = 0;
-    rec[0] = r;
-    stub[0] = gw_stub(false, true, 0, budget, 0);
+    stub[0] = gw_stub(false, true, 0, budget, GW_SPILL, 0);
     const uint32_t at = GW_ATOMIC_ADD(tail, 1u);
-    ring[at & (GW_RING - 1)] = gw_item(g, 0, 0);
+    ring[at & ring_mask] = gw_item(g, 0, 0);
     return true;
 }
 
 // ---- phase 1: take an item; the entry's position; the id of the child it stands for -------------------------------
-template <int NW>
-AR_HD void gw_fetch(GwLane<NW>& ln, uint32_t item, const GwGame<NW>* games, const GwRec<NW>* rec /*[G][SLOTS]*/,
+template <int NW, int R>
+AR_HD void gw_fetch(GwLane<NW>& ln, uint32_t item, const GwGame<NW>* games, const GwRec<NW>* rec /*[G][R]*/,
                     const uint32_t* stub /*[G][SLOTS]*/, const uint32_t* stub_node /*[G][SLOTS]*/, const GwMem<NW>& m) {
-    ln.g = item & 0xffu;
+    ln.g = item & 0x7fu;
     ln.t = (item >> 8) & 0xfu;
+    const uint32_t rem = (item >> 12) & 0xfu;
     const uint32_t st = stub[ln.g * GW_SLOTS + ln.t];
     ln.child = st & 1u;
     ln.from_pick = (st >> 1) & 1u;
     ln.idx = (st >> 2) & 31u;
     ln.k = (st >> 7) & 31u;
-    const uint32_t pslot = (st >> 12) & 15u;
+    const uint32_t ref = (st >> 12) & 7u, rslot = (st >> 15) & 15u;
     const GwGame<NW>& G = games[ln.g];
-    const GwRec<NW>& R = rec[ln.g * GW_SLOTS + (ln.child ? pslot : ln.t)];
-    ln.pos = R.pos;
-    ln.node = R.node;
     ln.parent = NIL;
     ln.r1 = ln.r2 = 0.0f;
+    ln.free_ref = GW_SPILL;
+    if (ln.from_pick) {
+        ln.pos = G.root_st;
+        ln.node = G.root;
+        return;
+    }
+    GwRec<NW> Rc;
+    if (ref < (uint32_t)R) Rc = rec[ln.g * R + ref];
+    else Rc = m.spill(G)[rslot];
+    // the last reader of a record in LDS releases it: the last of the siblings, or the re-queued entry itself
+    if (ref < (uint32_t)R && (!ln.child || rem == 0)) ln.free_ref = ref;
+    ln.pos = Rc.pos;
+    ln.node = Rc.node;
     if (ln.child) {
-        ln.parent = R.node;
+        ln.parent = Rc.node;
         const uint32_t o1 = ln.idx / 5, o2 = ln.idx % 5;
-        st_step(G.board, m.cost(G), ln.pos, outcome_action(R.omap0, o1), outcome_action(R.omap1, o2), ln.r1, ln.r2);
+        st_step(G.board, m.cost(G), ln.pos, outcome_action(Rc.omap0, o1), outcome_action(Rc.omap1, o2), ln.r1, ln.r2);
         ln.node = stub_node[ln.g * GW_SLOTS + ln.t];  // NIL: no such child yet
     }
 }
 
 // ---- phase 2: look at the node (search.rs:591-636 root, :675-725 child, :742-817 build_gather_level) ---------------
 template <int NW>
-AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, const GwMem<NW>& m, const SearchCfg& cfg, const GwOutcomeTable* otab) {
+AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, uint32_t* rec_owner /*[R] of the game*/, const GwMem<NW>& m,
+                    const SearchCfg& cfg, const GwOutcomeTable* otab) {
+    if (ln.free_ref != GW_SPILL) rec_owner[ln.free_ref] = 0;  // (every reader of it ran phase 1 of this pass)
     ln.is_final = ln.wait = ln.interior = false;
     ln.fin_node = NIL;
     ln.fin_kind = PROC_NONE;
@@ -423,6 +450,10 @@ AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, const GwMem<NW>& m, const Sea
         const NodeH0 a = N.h0;
         const NodeH1 b = N.h1;
         const NodeH2 c = N.h2;
+#if defined(AR_STATS) && defined(__HIP_DEVICE_COMPILE__)
+        ln.dbg_steps = 0;
+        ln.dbg_t[0] = ln.dbg_t[1] = ln.dbg_t[2] = (a.visits + c.terminal + e1[4].visits + e2[4].visits) ? wall_clock64() : wall_clock64() + 0;
+#endif
         // its child table rides along in the same round trip (used if the node turns out to be interior)
         uint32_t kid_in[25];
 #pragma unroll
@@ -452,6 +483,9 @@ AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, const GwMem<NW>& m, const Sea
             uint32_t left = ln.k, mask = 0;
             uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
             bool wait = false;
+#if defined(AR_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            ln.dbg_t[1] = (h1.score[0] + h2.score[0] + h1.score[4] + h2.score[4]) != 12345.0f ? wall_clock64() : 0;
+#endif
             Rng rng = G.rng;
             bool drew = false;
             while (left > 0) {
@@ -474,7 +508,13 @@ AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, const GwMem<NW>& m, const Sea
                 gw_half_take(h1, b1, kk);
                 gw_half_take(h2, b2, kk);
                 left -= kk;
+#if defined(AR_STATS) && defined(__HIP_DEVICE_COMPILE__)
+                ln.dbg_steps += 1;
+#endif
             }
+#if defined(AR_STATS) && defined(__HIP_DEVICE_COMPILE__)
+            ln.dbg_t[2] = (mask + left) != 0xFFFFFFF0u ? wall_clock64() : 0;
+#endif
             if (wait) {
                 ln.wait = true;  // nothing was written, nothing was drawn: the entry runs again later
                 return;
@@ -503,39 +543,73 @@ AR_HD void gw_visit(GwLane<NW>& ln, GwGame<NW>& G, const GwMem<NW>& m, const Sea
             for (int j = 0; j < 25; ++j) ln.kid[j] = kid_in[j];
         }
     }
-    if (ln.is_final && ln.fin_kind == PROC_EVAL) {
-        ln.arr = GW_ATOMIC_ADD(&G.b_nn, 1u);
-        m.leaves(G)[ln.arr] = ln.pos;  // evaluation requests in arrival order; the batch entry says which one is its
+    if (ln.is_final) {
+        // the batch entry (search.rs:598-633, 681-701) and the collision record, in arrival order; the entry carries its
+        // place in the depth-first order (pick number, visit slot) and the index of its evaluation request
+        if (ln.fin_kind != PROC_NONE) {
+            uint32_t word = ln.fin_kind;
+            if (ln.fin_kind == PROC_EVAL) {
+                ln.arr = GW_ATOMIC_ADD(&G.b_nn, 1u);
+                m.leaves(G)[ln.arr] = ln.pos;
+                word |= ln.arr << 8;
+            } else {
+                GW_ATOMIC_ADD(&G.b_term, 1u);
+            }
+            const uint32_t i = GW_ATOMIC_ADD(&G.n_proc, 1u);
+            if (i >= cfg.batch_size) {
+                G.error = 1;
+            } else {
+                ProcEntry pe;
+                pe.node = ln.fin_node;
+                pe.kind = word | ((((uint32_t)G.pick << 4) | ln.t) << 16);
+                m.proc(G)[i] = pe;
+            }
+        }
+        if (ln.coll_mv) {
+            GW_ATOMIC_ADD(&G.pick_mv, ln.coll_mv);
+            const uint32_t j = GW_ATOMIC_ADD(&G.n_coll, 1u);
+            if (j >= m.coll_cap) {
+                G.error = 2;
+            } else {
+                CollEntry ce;
+                ce.node = ln.fin_node;
+                ce.mv = ln.coll_mv;
+                m.coll(G)[j] = ce;
+            }
+        }
     }
 }
 
 // ---- phase 3: publish: children into the queue / the entry back into the queue / the final record -----------------
 // Returns true for the lane whose entry completed the pick (it runs gw_finish_pick).
-template <int NW>
-AR_HD bool gw_publish(const GwLane<NW>& ln, GwGame<NW>& G, GwRec<NW>* rec /*[SLOTS] of the game*/, uint32_t* stub,
-                      uint32_t* stub_node, GwFin* fin, uint16_t* ring, uint32_t* tail) {
+template <int NW, int R>
+AR_HD bool gw_publish(const GwLane<NW>& ln, GwGame<NW>& G, GwRec<NW>* rec /*[R] of the game*/, uint32_t* rec_owner,
+                      GwRec<NW>* spill /*[SLOTS] of the game, global*/, uint32_t* stub, uint32_t* stub_node,
+                      uint16_t* ring, uint32_t ring_mask, uint32_t* tail) {
     if (ln.is_final) {
-        GwFin f;
-        f.node = ln.fin_node;
-        f.info = 0x80000000u | ln.fin_kind | (ln.coll_mv << 8) | (ln.arr << 16);
-        fin[ln.t] = f;
-        GW_ATOMIC_OR(&G.lead_mask, 1u << ln.t);
         const uint32_t bits = ((1u << ln.k) - 1u) << ln.t;
         const uint32_t old = GW_ATOMIC_OR(&G.final_mask, bits);
         const uint32_t full = (1u << G.budget) - 1u;
         return (old | bits) == full && old != full;
     }
+    // the entry's record (its children step from it; a re-queued entry starts from it again): one of the game's
+    // records in LDS if one is free, else the game's scratch
     GwRec<NW> r;
     r.pos = ln.pos;
     r.omap0 = ln.interior ? ln.omap0 : 0u;
     r.omap1 = ln.interior ? ln.omap1 : 0u;
     r.node = ln.node;
     r.pad = 0;
-    rec[ln.t] = r;
+    uint32_t ref = GW_SPILL;
+    for (uint32_t j = 0; j < (uint32_t)R; ++j) {
+        if (ref == GW_SPILL && GW_ATOMIC_CAS(&rec_owner[j], 0u, ln.t + 1u) == 0u) ref = j;
+    }
+    if (ref != GW_SPILL) rec[ref] = r;
+    else spill[ln.t] = r;
     if (ln.wait) {
-        stub[ln.t] = gw_stub(false, false, 0, ln.k, 0);
+        stub[ln.t] = gw_stub(false, false, 0, ln.k, ref, ln.t);
         const uint32_t at = GW_ATOMIC_ADD(tail, 1u);
-        ring[at & (GW_RING - 1)] = gw_item(ln.g, ln.t, 0);
+        ring[at & ring_mask] = gw_item(ln.g, ln.t, 0);
         return false;
     }
     // children in child-slot order take consecutive runs of this entry's visit slots
@@ -549,56 +623,31 @@ AR_HD bool gw_publish(const GwLane<NW>& ln, GwGame<NW>& G, GwRec<NW>* rec /*[SLO
         mm &= mm - 1;
         const uint32_t kj = (gw_sel5u(ln.vtp, idx / 5) >> (6u * (idx % 5))) & 63u;
         left -= 1;
-        stub[slot] = gw_stub(true, false, idx, kj, ln.t);
+        stub[slot] = gw_stub(true, false, idx, kj, ref, ln.t);
         stub_node[slot] = gw_pick25(ln.kid, idx);
-        ring[at & (GW_RING - 1)] = gw_item(ln.g, slot, left);
+        ring[at & ring_mask] = gw_item(ln.g, slot, left);
         at += 1;
         slot += kj;
     }
     return false;
 }
 
-// ---- the end of a pick_nodes_to_extend call: batch entries and collision records in depth-first order, then the
-// outer loop of simulate_batch (search.rs:981-999) ------------------------------------------------------------------
+// ---- the end of a pick_nodes_to_extend call: the outer loop of simulate_batch (search.rs:981-999) ------------------
+// `go_on` false: the launch has used up its passes; a gather that is not complete is parked here, between two picks (all
+// its entries are final, everything it did is in the tree), and the next launch continues it. Which launch runs which pick
+// does not change what a pick does.
 template <int NW>
-AR_HD void gw_finish_pick(GwGame<NW>& G, GwRec<NW>* rec, uint32_t* stub, GwFin* fin, uint16_t* ring, uint32_t* tail,
-                          uint32_t g, const GwMem<NW>& m, const SearchCfg& cfg) {
-    ProcEntry* proc = m.proc(G);
-    CollEntry* coll = m.coll(G);
-    uint32_t lead = G.lead_mask, pick_mv = 0;
-    while (lead) {
-        const uint32_t t = (uint32_t)lowest_bit(lead);
-        lead &= lead - 1;
-        const GwFin f = fin[t];
-        const uint32_t kind = f.info & 0xffu, mv = (f.info >> 8) & 0xffu, arr = (f.info >> 16) & 0xffu;
-        if (kind != PROC_NONE) {
-            if (G.n_proc >= cfg.batch_size) {
-                G.error = 1;
-            } else {
-                ProcEntry pe;
-                pe.node = f.node;
-                pe.kind = kind == PROC_EVAL ? kind | (arr << 8) : kind;
-                proc[G.n_proc] = pe;
-                G.n_proc += 1;
-                if (kind != PROC_EVAL) G.b_term += 1;
-            }
-        }
-        if (mv) {
-            pick_mv += mv;
-            if (G.n_coll >= m.coll_cap) {
-                G.error = 2;
-            } else {
-                CollEntry ce;
-                ce.node = f.node;
-                ce.mv = mv;
-                coll[G.n_coll] = ce;
-                G.n_coll += 1;
-            }
-        }
+AR_HD void gw_finish_pick(GwGame<NW>& G, uint32_t* stub, uint16_t* ring, uint32_t ring_mask, uint32_t* tail, uint32_t g,
+                          bool go_on) {
+    G.b_coll += G.pick_mv;
+    G.left -= (int32_t)G.pick_mv;
+    G.pick_mv = 0;
+    if (!go_on && G.n_proc < G.batch && G.left > 0) {
+        G.running = 0;
+        G.parked = 1;
+        return;
     }
-    G.b_coll += pick_mv;
-    G.left -= (int32_t)pick_mv;
-    gw_next_pick(G, rec, stub, ring, tail, g);
+    gw_next_pick(G, stub, ring, ring_mask, tail, g);
 }
 
 // Starts one simulate_batch's gather for a game context (gather_begin, dev_search.h). `S` is the game's slot.
@@ -614,24 +663,35 @@ AR_HD void gw_begin(GwGame<NW>& G, const Slot<NW>& S, uint32_t slot, const Searc
     G.cap = S.cap;
     G.node_count = S.node_count;
     G.n_proc = G.n_coll = G.b_nn = G.b_term = G.b_coll = 0;
+    G.parked = 0;
     G.batch = S.remaining < cfg.batch_size ? S.remaining : cfg.batch_size;
     G.budget = 0;
+    G.pick = 0;
     G.pick_mv = 0;
-    G.final_mask = G.lead_mask = 0;
+    G.final_mask = 0;
     G.error = 0;
     G.d_new = G.d_visits = 0;
     G.running = 0;
     G.stalled = 0;
     G.began = 0;
-    G.eval_base = 0;
     G.left = 0;
-    if (G.hi + G.batch > G.cap) {
+    if (G.hi + G.batch > G.cap && !S.gather_pending) {  // (a parked gather passed this check when it began)
         G.stalled = 1;
         return;
     }
-    G.left = (int32_t)collisions_left(G.node_count, cfg);
     G.began = 1;
     G.running = 1;
+    if (S.gather_pending) {  // a parked gather: where it stood after its last pick
+        G.n_proc = S.n_proc;
+        G.n_coll = S.n_coll;
+        G.b_nn = S.b_nn;
+        G.b_term = S.b_term;
+        G.b_coll = S.b_coll;
+        G.left = S.g_left;
+        G.pick = (uint8_t)S.g_pick;
+        return;
+    }
+    G.left = (int32_t)collisions_left(G.node_count, cfg);
 }
 
 // The end of a game's gather: what the slot header takes back (the tail of k_gather8).
@@ -646,16 +706,22 @@ AR_HD void gw_end(const GwGame<NW>& G, Slot<NW>& S, const SearchCfg& cfg) {
     S.node_count = G.node_count;
     S.new_nodes += G.d_new;
     S.nv_gather += G.d_visits;
-    S.n_proc = G.n_proc;
+    S.n_proc = G.n_proc < cfg.batch_size ? G.n_proc : cfg.batch_size;  // (the error paths keep counting)
     S.n_coll = G.n_coll;
     S.b_nn = G.b_nn;
     S.b_term = G.b_term;
     S.b_coll = G.b_coll;
-    S.batch_active = 1;
-    S.eval_base = G.eval_base;
     S.rng = G.rng;
-    S.gather_pending = 0;
     S.g_rounds = 0;
+    if (G.parked) {
+        S.gather_pending = 1;
+        S.g_left = G.left;
+        S.g_pick = G.pick;
+        if (G.error) S.error = G.error;
+        return;
+    }
+    S.batch_active = 1;
+    S.gather_pending = 0;
     if (G.error) S.error = G.error;
     else if (G.running) S.error = 8;  // the queue ran dry with the gather unfinished (a bug guard)
 }

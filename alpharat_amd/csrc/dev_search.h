@@ -77,10 +77,14 @@ enum { PROC_TERMINAL = 0, PROC_EVAL = 1 };
 
 struct ProcEntry {
     uint32_t node;
-    uint32_t kind;  // PROC_TERMINAL, or PROC_EVAL | (index of the leaf's evaluation in this batch's requests) << 8
+    // PROC_TERMINAL or PROC_EVAL | (index of the leaf's evaluation in this batch's requests) << 8 | order key << 16: the
+    // backup takes a batch's entries by increasing key (the depth-first gathers write them in that order: key = index;
+    // the work-queue gather writes them as their leaves are reached: key = pick number, visit slot)
+    uint32_t kind;
 };
 AR_HD uint32_t proc_kind(uint32_t k) { return k & 0xffu; }
-AR_HD uint32_t proc_eval_index(uint32_t k) { return k >> 8; }
+AR_HD uint32_t proc_eval_index(uint32_t k) { return (k >> 8) & 0xffu; }
+AR_HD uint32_t proc_key(uint32_t k) { return k >> 16; }
 struct CollEntry {
     uint32_t node;
     uint32_t mv;
@@ -145,8 +149,11 @@ struct alignas(128) Slot {
     uint64_t nv_gather, nv_backup, new_nodes;
     MoveResult last;  // result of the last finished search
     uint32_t error;   // non-zero: internal capacity violation (bug guard)
-    uint32_t gather_pending;  // 1: a gather was cut off at the round limit, its lane state is in Mem::glane
-    uint32_t g_rounds;        // rounds the game's last complete gather took (scheduling hint: which kernel walks it next)
+    uint32_t gather_pending;  // 1: a gather was cut off at the round limit (lane kernel: its state is in Mem::glane;
+                              // work-queue kernel: between two pick_nodes_to_extend calls, counters below)
+    uint32_t g_rounds;        // rounds the game's last complete gather took (scheduling hint)
+    int32_t g_left;           // parked work-queue gather: collision budget left, number of the last pick
+    uint32_t g_pick;
 };
 
 // resolved addresses of one game's memory (built per kernel from kernel arguments + slot offsets)
@@ -277,7 +284,8 @@ AR_HD uint32_t collisions_left(uint32_t node_count, const SearchCfg& c) {
     if (node_count >= c.coll_end) return c.coll_max;
     if (node_count <= c.coll_start) return c.coll_min;
     const float ratio = (float)(node_count - c.coll_start) / (float)(c.coll_end - c.coll_start);
-    const float scaled = (float)c.coll_min + ((float)c.coll_max - (float)c.coll_min) * powf(ratio, c.coll_power);
+    // (x^1 = x in every libm; spelled out because the device's pow is a long routine that every game would run)
+    const float scaled = (float)c.coll_min + ((float)c.coll_max - (float)c.coll_min) * (c.coll_power == 1.0f ? ratio : powf(ratio, c.coll_power));
     const float r = roundf(scaled);
     uint32_t v = r <= 0.0f ? 0u : (r >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)r);
     if (v < c.coll_min) v = c.coll_min;
@@ -492,7 +500,7 @@ AR_HD void emit_proc(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, int ev
     const uint32_t i = s.n_proc++;
     ProcEntry pe;
     pe.node = node;
-    pe.kind = kind == PROC_EVAL ? kind | (s.b_nn << 8) : kind;
+    pe.kind = (kind == PROC_EVAL ? kind | (s.b_nn << 8) : kind) | (i << 16);
     m.proc[i] = pe;
     if (kind == PROC_EVAL) {
         const uint32_t j = s.b_nn++;
@@ -1015,9 +1023,24 @@ AR_HD bool batch_end(Slot<NW>& s) {
     return s.remaining == 0;
 }
 
+// The batch entries in backup order (by key; a no-op for the depth-first gathers, whose entries are written in order).
+template <int NW>
+AR_HD void proc_sort(const Slot<NW>& s, const Mem<NW>& m) {
+    for (uint32_t i = 1; i < s.n_proc; ++i) {
+        const ProcEntry pe = m.proc[i];
+        uint32_t j = i;
+        while (j > 0 && proc_key(m.proc[j - 1].kind) > proc_key(pe.kind)) {
+            m.proc[j] = m.proc[j - 1];
+            j -= 1;
+        }
+        if (j != i) m.proc[j] = pe;
+    }
+}
+
 // backup of one simulate_batch for every lane of the wavefront (split kernels)
 template <int NW>
 AR_HD bool backup_machine(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg, const EvalOut* ev, const ZigTables* zt) {
+    proc_sort(s, m);
     BackupLane b;
     backup_begin(b);
     for (;;) {

@@ -28,7 +28,10 @@ inline SlotLayout make_layout(const SearchCfg& cfg, uint32_t max_turns) {
     // aligned, is the larger one)
     const size_t level_o = align_up(16 + 112 + sizeof(State<NW>), 16);
     const size_t level_bytes = sizeof(Level<NW>) > level_o ? sizeof(Level<NW>) : level_o;
-    off = align_up(off + level_bytes * L.max_depth, 64);
+    // (the work-queue gather, dev_gatherw.h, keeps up to sixteen spilled position records here instead: State + 16 bytes each)
+    const size_t spill_bytes = 16 * align_up(sizeof(State<NW>) + 16, 8);
+    const size_t levels_total = level_bytes * L.max_depth > spill_bytes ? level_bytes * L.max_depth : spill_bytes;
+    off = align_up(off + levels_total, 64);
     L.ev_off = off;
     off = align_up(off + sizeof(EvalOut) * cfg.batch_size, 64);
     L.leaf_off = off;

@@ -87,9 +87,12 @@ static void grow(HsRun* r) {
 // The work-queue gather (dev_gatherw.h) run the way a wavefront runs it: every pass takes a run of queued items (never
 // splitting the children of one parent), then phase by phase, lane after lane. `sched` varies how many items a pass
 // takes (1 = as many as 64 lanes can; otherwise a seeded random cut), so the result is checked not to depend on it.
-static bool wide_gather(HsRun* r, uint64_t& sched) {
-    typedef GwShared<4, 1> Sh;
+}  // extern "C"
+template <int R>
+static bool wide_gather(HsRun* r, uint64_t& sched, uint32_t pass_limit) {
+    typedef GwShared<4, 1, R> Sh;
     static thread_local Sh sh;
+    const uint32_t ring_mask = Sh::RING - 1;
     Slot<4>& s = r->slot;
     GwMem<4> m;
     m.arena = r->arena.data();
@@ -99,12 +102,14 @@ static bool wide_gather(HsRun* r, uint64_t& sched) {
     m.proc_off = (uint32_t)r->L.proc_off;
     m.coll_off = (uint32_t)r->L.coll_off;
     m.leaf_off = (uint32_t)r->L.leaf_off;
+    m.spill_off = (uint32_t)r->L.levels_off;
     m.coll_cap = r->L.coll_cap;
     GwGame<4>& G = sh.game[0];
     gw_begin(G, s, 0, r->cfg);
     sh.tail = 0;
+    for (int j = 0; j < R; ++j) sh.rec_owner[0][j] = 0;
     uint32_t head = 0;
-    if (G.began) gw_next_pick(G, sh.rec[0], sh.stub[0], sh.ring, &sh.tail, 0);
+    if (G.began) gw_next_pick(G, sh.stub[0], sh.ring, ring_mask, &sh.tail, 0);
     GwLane<4> lanes[64];
     bool finisher[64];
     uint64_t passes = 0;
@@ -116,7 +121,7 @@ static bool wide_gather(HsRun* r, uint64_t& sched) {
         }
         // whole sibling groups only
         while (true) {
-            const uint32_t last = sh.ring[(head + take - 1) & (GW_RING - 1)];
+            const uint32_t last = sh.ring[(head + take - 1) & ring_mask];
             const uint32_t rem = (last >> 12) & 15u;
             if (rem == 0) break;
             take += rem;
@@ -124,7 +129,7 @@ static bool wide_gather(HsRun* r, uint64_t& sched) {
         if (take > 64) {  // a group that does not fit behind the cut: stop in front of it
             uint32_t t2 = 0;
             while (true) {
-                const uint32_t it = sh.ring[(head + t2) & (GW_RING - 1)];
+                const uint32_t it = sh.ring[(head + t2) & ring_mask];
                 const uint32_t rem = (it >> 12) & 15u;
                 if (t2 + rem + 1 > 64) break;
                 t2 += rem + 1;
@@ -133,18 +138,20 @@ static bool wide_gather(HsRun* r, uint64_t& sched) {
         }
         for (uint32_t l = 0; l < take; ++l) {
             lanes[l].active = true;
-            gw_fetch(lanes[l], sh.ring[(head + l) & (GW_RING - 1)], sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
+            gw_fetch<4, R>(lanes[l], sh.ring[(head + l) & ring_mask], sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
         }
         head += take;
-        for (uint32_t l = 0; l < take; ++l) gw_visit(lanes[l], sh.game[lanes[l].g], m, r->cfg, (const GwOutcomeTable*)nullptr);
+        for (uint32_t l = 0; l < take; ++l)
+            gw_visit(lanes[l], sh.game[lanes[l].g], sh.rec_owner[lanes[l].g], m, r->cfg, (const GwOutcomeTable*)nullptr);
         for (uint32_t l = 0; l < take; ++l) {
             const uint32_t g = lanes[l].g;
-            finisher[l] = gw_publish(lanes[l], sh.game[g], sh.rec[g], sh.stub[g], sh.stub_node[g], sh.fin[g], sh.ring, &sh.tail);
+            finisher[l] = gw_publish<4, R>(lanes[l], sh.game[g], sh.rec[g], sh.rec_owner[g], m.spill(sh.game[g]), sh.stub[g],
+                                           sh.stub_node[g], sh.ring, ring_mask, &sh.tail);
         }
         for (uint32_t l = 0; l < take; ++l)
             if (finisher[l]) {
                 const uint32_t g = lanes[l].g;
-                gw_finish_pick(sh.game[g], sh.rec[g], sh.stub[g], sh.fin[g], sh.ring, &sh.tail, g, m, r->cfg);
+                gw_finish_pick(sh.game[g], sh.stub[g], sh.ring, ring_mask, &sh.tail, g, passes + 1 < pass_limit);
             }
         passes += 1;
     }
@@ -155,8 +162,9 @@ static bool wide_gather(HsRun* r, uint64_t& sched) {
         s.status = SLOT_STALL;
         return false;
     }
-    return true;
+    return !G.parked;  // (parked at the pass limit: the next call continues the gather)
 }
+extern "C" {
 
 // A stand-in for a network in the CPU harness: priors and values that are a fixed hash of the position, so that (unlike
 // uniform priors) outcomes almost never tie -- the regime the network-driven self-play runs in. tests/_hostsim.py
@@ -221,8 +229,8 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
     start_game(s, r->mem(), r->cfg);
     const int mode = eval_mode == 0 ? EVAL_UNIFORM : EVAL_STORE;
     std::vector<EvalOut> ev(batch);
-    uint64_t wide_sched = (eval_mode == 5 || eval_mode == 7) ? (seed | 2) : 1;
-    const bool hashed = eval_mode >= 6;  // 6, 7: work-queue gather; 8: lane gather -- evaluations from hashed_eval
+    uint64_t wide_sched = (eval_mode == 5 || eval_mode == 7 || eval_mode == 9) ? (seed | 2) : 1;
+    const bool hashed = eval_mode >= 6;  // 6, 7, 9: work-queue gather; 8: lane gather -- evaluations from hashed_eval
     while (s.status == SLOT_ACTIVE || s.status == SLOT_STALL || s.status == SLOT_ADVANCE) {
         if (s.status == SLOT_STALL) {
             grow(r);
@@ -237,8 +245,10 @@ void* hs_run(const HsGame* g, const HsCfg* c, uint32_t n_sims, uint32_t batch, u
             fused_machine(s, m, r->cfg, &g_zig, 3);
             continue;
         }
-        if (eval_mode == 4 || eval_mode == 5 || eval_mode == 6 || eval_mode == 7) {  // the work-queue gather (dev_gatherw.h); 5, 7: random cuts of the queue
-            if (!wide_gather(r, wide_sched)) continue;
+        if (eval_mode == 9) {  // the work-queue gather with one position record per game in "LDS": the others go through the scratch
+            if (!wide_gather<1>(r, wide_sched, 6)) continue;  // (and a limit of six passes per call: gathers are parked and resumed)
+        } else if (eval_mode == 4 || eval_mode == 5 || eval_mode == 6 || eval_mode == 7) {  // the work-queue gather (dev_gatherw.h); 5, 7: random cuts of the queue
+            if (!wide_gather<4>(r, wide_sched, 0xFFFFFFFFu)) continue;
         } else if (eval_mode == 3) {  // the self-play kernel's gather: cut off every few rounds, parked, resumed
             const int got = gather_machine_limited(s, m, r->cfg, mode, 7);
             if (got != GATHER_COMPLETE) continue;

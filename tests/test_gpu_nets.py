@@ -156,6 +156,7 @@ def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
                 dict(AR_GATHER="octet3"), dict(AR_GATHER="octet3", AR_GROUPS=2),
                 dict(AR_GATHER="wide"), dict(AR_GATHER="wide", AR_GROUPS=2), dict(AR_GATHER="wide", AR_GW_WAVES=1),
                 dict(AR_GATHER="wide", AR_GW_WAVES=3, AR_GROUPS=3, AR_NO_ADVANCE_OVERLAP=1),
+                dict(AR_GATHER="wide", AR_GW_PASSES=7), dict(AR_GATHER="wide", AR_GW_PASSES=23, AR_GROUPS=2, AR_GW_WAVES=2),
                 dict(AR_BACKUP="lane"), dict(AR_BACKUP="lane", AR_GATHER="lane"), dict(AR_BACKUP="group", AR_GATHER="lane", AR_GROUPS=2)):
         other = run(**env)
         assert sorted(other) == sorted(base)

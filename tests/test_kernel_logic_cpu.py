@@ -76,6 +76,28 @@ def test_whole_game_tuned_noise_7x7_and_split_eval_path():
     _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=2))
     # gather cut off every 7 rounds and resumed from its parked lane state
     _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=3))
+    # the work-queue gather (dev_gatherw.h), run pass by pass like a wavefront runs it; with uniform priors nearly
+    # every allocation step draws a tie break, so entries wait for the depth-first order all the time
+    _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=4))
+    # ... and with random cuts of its queue (a pass takes fewer items than it could)
+    _same_game(want, H.run(g, 50, cfg, 400, 16, 77, eval_mode=5))
+
+
+@pytest.mark.parametrize("sims,batch,seed", [(1897, 16, 77), (300, 8, 5), (150, 3, 9)])
+def test_work_queue_gather_with_network_like_priors(sims, batch, seed):
+    """The work-queue gather in the regime it is built for: priors and values that differ from outcome to outcome
+    (a fixed hash of the position stands in for the network, on both sides), so ties are rare and the levels of a
+    pick really run side by side. Whole-game records against the oracle: queue taken 64 at a time, with random cuts,
+    and with a single position record per game (every other parent's record goes through the scratch area)."""
+    g = O.Game(7, 7, 50).random_cheese(10, True, seed)
+    cfg = O.make_config(noise_epsilon=0.25, **TUNED)
+    want = O.play_game(g, cfg, sims, batch, seed, backend=4, net=O.CallbackBackend(H.hashed_eval(7)))
+    assert want["total_nn_evals"] > 0
+    _same_game(want, H.run(g, 50, cfg, sims, batch, seed, eval_mode=8))  # the lane-per-game gather on the same evaluator
+    for mode in (6, 7, 9):
+        got = H.run(g, 50, cfg, sims, batch, seed, eval_mode=mode)
+        _same_game(want, got)
+        assert got["wide_gathers"] > 0
 
 
 def test_arena_growth_keeps_results():
