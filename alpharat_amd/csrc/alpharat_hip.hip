@@ -88,20 +88,32 @@ struct DoneInfo {
     MoveResult last;
 };
 
-// Overflow blocks for trees that outgrow their first arena. Three size classes (2x, 4x, 8x the
-// first arena) carved once from the same allocation as the first arenas; free blocks sit on one
-// device-side stack per class. Kernels only POP from the free stacks and only APPEND to the return
-// lists, and k_pool_merge (launched between batches of tree kernels) moves returned blocks back to
-// the stacks -- so a block is never handed out while an earlier kernel may still read it, and no
-// stack sees a concurrent push and pop.
-enum { POOL_CLASSES = 3 };
+// Where the trees live. One allocation per device holds every game's arena, cut into PAGES of 768 nodes (243 KB with
+// the nodes' share of the re-rooting table); a game owns one run of consecutive pages at a time, exactly as many as its
+// kept tree plus one full search needs, and changes run when tree reuse re-roots the tree (k_advance rewrites every kept
+// node anyway). A resident game so costs what its tree needs -- not a fixed first arena plus overflow blocks (rounds 1-2:
+// 3.7 MB per game for 1.7 MB of live nodes, which capped the device at 65536 games).
+// Which pages are taken is a bitmap, 64 pages to a word; a run lies inside one word (at most 64 pages = 49152 nodes;
+// bigger trees get an arena from the host), so finding n free pages is bit arithmetic on one word and claiming them one
+// atomic OR -- and pages that come back merge with their free neighbours by themselves (size classes with free lists
+// were tried first: a session's games start in step, every class sees its peak demand once, and the region ends up
+// cut into blocks of sizes nobody wants any more).
+// Kernels only CLAIM pages and only APPEND runs they leave to the return lists; k_pool_merge (ordered after the kernels
+// that could still read those pages) clears their bits -- so no page is handed out while an earlier kernel may read it.
+// The region is cut into ZONES, one per 1024 consecutive slots, each with its own bitmap: a wavefront (and a CU) works on
+// consecutive slots, and their trees then lie within a few GB of each other. With one pool for the whole device the
+// trees of neighbouring slots ended up anywhere in 260 GB and every kernel that walks trees ran 2-3x slower, more so
+// the longer the run (address translation: the big allocation is mapped with large fragments, and a CU that touches a
+// few of them is served from its translation cache).
+enum { POOL_PAGE_NODES = 768, POOL_WORD_PAGES = 64, POOL_ZONE_SLOTS = 1024 };
 struct ArenaPool {
-    long long off[POOL_CLASSES];      // byte offset of the class region from the arena base
-    uint32_t n[POOL_CLASSES];         // blocks in the class
-    uint32_t* free_ids[POOL_CLASSES]; // [n] stack of free block indices
-    uint32_t* ret_ids[POOL_CLASSES];  // [n] blocks handed back since the last merge
-    int* top;                         // [POOL_CLASSES] entries on each free stack
-    uint32_t* ret_n;                  // [POOL_CLASSES]
+    unsigned long long* bits;   // [zones x zone_words] bit set: page taken
+    unsigned long long* ret;    // [zones x ret_cap] runs left since the last merge: page index within the zone | pages << 32
+    uint32_t* ret_n;            // [zones]
+    uint32_t zone_words, zones, ret_cap;
+    uint32_t page_nodes;        // nodes per page (768; the AR_ARENA_NODES test knob makes pages small)
+    uint32_t fresh_pages;       // pages of a fresh game's arena
+    unsigned long long page_bytes, zone_bytes;  // zone z is [z * zone_bytes, (z + 1) * zone_bytes) of the region
 };
 
 // The cost tables are read once or twice in every round of a gather (the step into the next child), in front of the
@@ -116,66 +128,82 @@ struct Bases {
     const uint8_t* maze;     // cost tables
     uint32_t maze_stage;     // bytes of the whole maze pool when it is small enough to sit in LDS (else 0)
     SlotLayout L;
-    uint32_t cap0;           // nodes per first arena
     ArenaPool pool;
 };
 
-__device__ inline uint32_t pool_cap(const Bases& B, int cls) { return B.cap0 << (cls + 1); }
-__device__ inline uint32_t pool_pop(const ArenaPool& P, int cls) {
-    if (P.n[cls] == 0) return NIL;
-    const int i = atomicSub(&P.top[cls], 1) - 1;
-    if (i < 0) {
-        atomicAdd(&P.top[cls], 1);
-        return NIL;
+// pages for `need` nodes; 0 when no run can hold them (more than one word of pages)
+__device__ inline uint32_t pool_pages_for(const ArenaPool& P, uint32_t need) {
+    const uint32_t n = (need + P.page_nodes - 1) / P.page_nodes;
+    return n <= POOL_WORD_PAGES ? (n ? n : 1u) : 0u;
+}
+// A run of `n` free pages in the slot's zone: first fit from a start word that differs from slot to slot (games that
+// look at the same time then look at different words). Returns the first page's index within the zone, NIL if none.
+// Called by one thread.
+__device__ inline uint32_t pool_claim(const ArenaPool& P, uint32_t slot, uint32_t n) {
+    const uint32_t zone = slot / POOL_ZONE_SLOTS;
+    unsigned long long* words = P.bits + (size_t)zone * P.zone_words;
+    const unsigned long long run = n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL);
+    uint32_t w = (slot * 7u) % P.zone_words;
+    for (uint32_t tries = 0; tries < P.zone_words; ++tries, w = w + 1 == P.zone_words ? 0 : w + 1) {
+        for (int again = 0; again < 4; ++again) {  // (a few retries on a word others are claiming from too)
+            const unsigned long long taken = __hip_atomic_load(&words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long m = ~taken;  // bit p survives when pages p .. p + n - 1 are all free
+            for (uint32_t len = 1; len < n && m;) {
+                const uint32_t sh = len < n - len ? len : n - len;
+                m &= m >> sh;
+                len += sh;
+            }
+            if (!m) break;
+            const uint32_t pos = (uint32_t)__ffsll((long long)m) - 1u;
+            const unsigned long long mask = run << pos;
+            const unsigned long long old = atomicOr(&words[w], mask);
+            if ((old & mask) == 0) return w * POOL_WORD_PAGES + pos;
+            atomicAnd(&words[w], ~(mask & ~old));  // someone was faster on part of it: give back what was ours, look again
+        }
     }
-    return __hip_atomic_load(&P.free_ids[cls][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return NIL;
 }
-__device__ inline void pool_give_back(const ArenaPool& P, uint32_t blk) {  // blk = Slot::pool_blk
-    const int cls = (int)(blk >> 24) - 1;
-    P.ret_ids[cls][atomicAdd(&P.ret_n[cls], 1u)] = blk & 0xFFFFFFu;
-}
-// smallest class holding `need` nodes, POOL_CLASSES if none does
-__device__ inline int pool_class_for(const Bases& B, uint32_t need) {
-    for (int c = 0; c < POOL_CLASSES; ++c)
-        if (pool_cap(B, c) >= need) return c;
-    return POOL_CLASSES;
-}
-// where a slot's arena fields point when it lives in its first arena / in pool block (cls, idx)
+// where a slot's arena fields point when it owns `n` pages from page `first` of its zone
 template <int NW>
-__device__ inline void slot_at_home(Slot<NW>& s, const Bases& B, uint32_t slot) {
-    const long long base = (long long)slot * (long long)arena_bytes(B.cap0);
-    s.cap = B.cap0;
-    s.stats_off = base;
-    s.fwd_off = base + (long long)B.cap0 * (long long)sizeof(NodeStats);
-    s.pool_blk = 0;
-}
-template <int NW>
-__device__ inline void slot_at_block(Slot<NW>& s, const Bases& B, int cls, uint32_t idx) {
-    const uint32_t cap = pool_cap(B, cls);
-    const long long base = B.pool.off[cls] + (long long)idx * (long long)arena_bytes(cap);
+__device__ inline void slot_at_pages(Slot<NW>& s, const Bases& B, uint32_t slot, uint32_t first, uint32_t n) {
+    const uint32_t cap = n * B.pool.page_nodes;
+    const long long base = (long long)((unsigned long long)(slot / POOL_ZONE_SLOTS) * B.pool.zone_bytes + (unsigned long long)first * B.pool.page_bytes);
     s.cap = cap;
     s.stats_off = base;
     s.fwd_off = base + (long long)cap * (long long)sizeof(NodeStats);
-    s.pool_blk = ((uint32_t)(cls + 1) << 24) | idx;
+    s.pool_blk = n;
 }
-// the arena a slot leaves behind: pool blocks go to the return list, host-grown ones are flagged
+// the arena a slot leaves behind: pages go to the return list of their zone, host-grown arenas are flagged
 template <int NW>
 __device__ inline void leave_arena(const Slot<NW>& old, Slot<NW>& s, const Bases& B) {
-    if (old.pool_blk) pool_give_back(B.pool, old.pool_blk);
-    else if (old.cap != B.cap0) s.release_grown = 1;
-}
-
-__global__ void k_pool_merge(ArenaPool P) {
-    const int c = blockIdx.x;
-    if (c >= POOL_CLASSES || P.n[c] == 0) return;
-    const uint32_t n = P.ret_n[c];
-    const int t = P.top[c];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) P.free_ids[c][t + (int)i] = P.ret_ids[c][i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        P.top[c] = t + (int)n;
-        P.ret_n[c] = 0;
+    if (old.pool_blk) {
+        const uint32_t zone = (uint32_t)((unsigned long long)old.stats_off / B.pool.zone_bytes);
+        const uint32_t first = (uint32_t)(((unsigned long long)old.stats_off - (unsigned long long)zone * B.pool.zone_bytes) / B.pool.page_bytes);
+        const uint32_t at = atomicAdd(&B.pool.ret_n[zone], 1u);
+        if (at < B.pool.ret_cap) B.pool.ret[(size_t)zone * B.pool.ret_cap + at] = (unsigned long long)first | ((unsigned long long)old.pool_blk << 32);
+        // (the list holds a run per slot of the zone and then some: more cannot be left between two merges)
+    } else if (old.cap != 0) {
+        s.release_grown = 1;
     }
+}
+// nodes a game needs room for when its kept tree has `cnt` nodes: the tree plus one full search
+__device__ inline uint32_t arena_need(uint32_t cnt, const SearchCfg& cfg) { return cnt + cfg.n_sims + 2 * cfg.batch_size + 64; }
+
+__global__ void k_pool_merge(ArenaPool P, uint32_t zone_first, uint32_t zone_count) {  // one block per zone
+    if (blockIdx.x >= zone_count) return;
+    const uint32_t zone = zone_first + blockIdx.x;
+    if (zone >= P.zones) return;
+    uint32_t n = P.ret_n[zone];
+    if (n > P.ret_cap) n = P.ret_cap;
+    unsigned long long* words = P.bits + (size_t)zone * P.zone_words;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long r = P.ret[(size_t)zone * P.ret_cap + i];
+        const uint32_t first = (uint32_t)r, pages = (uint32_t)(r >> 32);
+        const unsigned long long run = pages >= 64 ? ~0ULL : ((1ULL << pages) - 1ULL);
+        atomicAnd(&words[first / POOL_WORD_PAGES], ~(run << (first % POOL_WORD_PAGES)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) P.ret_n[zone] = 0;
 }
 
 // Slot ownership across the two streams of a group. The tree walks (k_gather, k_backup) own a slot
@@ -214,16 +242,35 @@ __global__ void k_init_games(Slot<NW>* slots, const GameInit<NW>* init, uint32_t
     if (i >= n) return;
     const GameInit<NW> gi = init[i];
     Slot<NW> s = slots[gi.slot];
-    // a new game starts in the slot's first arena (a host-grown arena was freed by the host already)
-    if (s.pool_blk) pool_give_back(B.pool, s.pool_blk);
-    slot_at_home(s, B, gi.slot);
+    // the block of the game that was here goes back (a host-grown arena was freed by the host already); the new game
+    // takes one for a fresh tree
+    if (s.pool_blk) {
+        Slot<NW> unused = s;
+        leave_arena(s, unused, B);
+    }
+    s.cap = 0;
+    s.pool_blk = 0;
     s.board = gi.board;
     s.st = gi.st;
     rng_seed(s.rng, gi.rng_seed);
     s.game_index = gi.game_index;
     s.single_search = gi.single;
-    const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, gi.slot, B.L, B.maze);
-    start_game(s, m, cfg);
+    const uint32_t off = pool_claim(B.pool, gi.slot, B.pool.fresh_pages);
+    if (off != NIL) {
+        slot_at_pages(s, B, gi.slot, off, B.pool.fresh_pages);
+        const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, gi.slot, B.L, B.maze);
+        start_game(s, m, cfg);
+    } else {
+        // no block right now: the game waits as a tree to be re-rooted from nothing; k_advance gives it its arena
+        // and its root when blocks have come back
+        start_game_header(s, cfg);
+        s.hi = 0;
+        s.root = 0;
+        s.node_count = 0;
+        s.stats_off = s.fwd_off = 0;
+        s.pending_root = NIL;
+        s.status = (!s.single_search && st_over(s.board, s.st)) ? (uint32_t)SLOT_DONE : (uint32_t)SLOT_ADVANCE;
+    }
     slots[gi.slot] = s;
 }
 
@@ -685,17 +732,13 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     const Mem<NW> m = resolve_mem<NW>(s, B.arena, B.scratch, slot, B.L, B.maze);
 
     if (status == tag_status(SLOT_STALL, phase)) {
-        const int want = pool_class_for(B, s.need_nodes > s.cap + 1 ? s.need_nodes : s.cap + 1);
-        int cls = POOL_CLASSES;
+        const uint32_t want = pool_pages_for(B.pool, s.need_nodes > s.cap + 1 ? s.need_nodes : s.cap + 1);
         uint32_t idx = NIL;
-        if (lane == 0)
-            for (cls = want; cls < POOL_CLASSES; ++cls)
-                if ((idx = pool_pop(B.pool, cls)) != NIL) break;
-        cls = __shfl(cls, 0, 64);
+        if (lane == 0 && want) idx = pool_claim(B.pool, slot, want);
         idx = (uint32_t)__shfl((int)idx, 0, 64);
         if (idx == NIL) return;  // nothing free: the host sees the stall and decides
         Slot<NW> d = s;
-        slot_at_block(d, B, cls, idx);
+        slot_at_pages(d, B, slot, idx, want);
         const Mem<NW> md = resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze);
         const uint4* ss = (const uint4*)m.stats;
         uint4* ds = (uint4*)md.stats;
@@ -709,14 +752,24 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     }
 
     const uint32_t keep_root = s.pending_root;
-    if (keep_root == NIL) {  // fresh root: back to the first arena
+    if (keep_root == NIL) {  // fresh root: the pages a fresh tree wants (the run it is in, if that is as many)
         if (lane == 0) {
             Slot<NW> d = s;
-            slot_at_home(d, B, slot);
-            leave_arena(s, d, B);
-            make_root(d, resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze));
-            d.status = ready_status;
-            slots[slot] = d;
+            const uint32_t want = B.pool.fresh_pages;
+            bool ok = s.cap != 0;
+            if (s.pool_blk != want) {  // (a bigger run, none, or an arena from the host)
+                const uint32_t off = pool_claim(B.pool, slot, want);
+                if (off != NIL) {
+                    slot_at_pages(d, B, slot, off, want);
+                    leave_arena(s, d, B);
+                    ok = true;
+                }
+            }
+            if (ok) {  // (an arena too small for a whole search stalls at its first gather and grows, like any other)
+                make_root(d, resolve_mem<NW>(d, B.arena, B.scratch, slot, B.L, B.maze));
+                d.status = ready_status;
+                slots[slot] = d;
+            }  // else: no arena yet; the slot stays as it is and the next launch of this parity tries again
         }
         return;
     }
@@ -764,28 +817,15 @@ __global__ void __launch_bounds__(64) k_advance(Slot<NW>* slots, uint32_t n_slot
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // destination arena: the smallest that holds the kept tree plus one search
-    const uint32_t need = cnt + cfg.n_sims + 2 * cfg.batch_size + 64;
-    const int cur = s.pool_blk ? (int)(s.pool_blk >> 24) - 1 : (s.cap == B.cap0 ? -1 : POOL_CLASSES /* host-grown */);
-    const int want = need <= B.cap0 ? -1 : pool_class_for(B, need);
+    const uint32_t want = pool_pages_for(B.pool, arena_need(cnt, cfg));  // (0: beyond a run; the tree stays where it is)
     Slot<NW> d = s;
     bool moved = false;
-    if (want == -1) {
-        if (cur != -1) {
-            slot_at_home(d, B, slot);
-            moved = true;
-        }
-    } else if (want < POOL_CLASSES && want != cur) {
-        // growing: any class from `want` up; shrinking: only classes below the current one
-        const int last = (cur > want && cur < POOL_CLASSES) ? cur - 1 : POOL_CLASSES - 1;
-        int cls = POOL_CLASSES;
+    if (want != 0 && want != s.pool_blk) {  // (pool_blk 0: an arena from the host)
         uint32_t idx = NIL;
-        if (lane == 0)
-            for (cls = want; cls <= last; ++cls)
-                if ((idx = pool_pop(B.pool, cls)) != NIL) break;
-        cls = __shfl(cls, 0, 64);
+        if (lane == 0) idx = pool_claim(B.pool, slot, want);
         idx = (uint32_t)__shfl((int)idx, 0, 64);
         if (idx != NIL) {
-            slot_at_block(d, B, cls, idx);
+            slot_at_pages(d, B, slot, idx, want);
             moved = true;
         }
     }
@@ -843,8 +883,10 @@ __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts
                        uint32_t* stall_list, uint32_t* release_list, ArenaPool P, unsigned long long* live) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = i < n_slots;
-    if (i == 0 && P.top)  // free overflow blocks per class, for the host's bookkeeping
-        for (int c = 0; c < POOL_CLASSES; ++c) counts[5 + c] = (uint32_t)(P.top[c] > 0 ? P.top[c] : 0);
+    if (in && P.bits && i < P.zones * P.zone_words) {  // for the host's bookkeeping: free pages of the region
+        const uint32_t free_pages = (uint32_t)__popcll(~P.bits[i]);
+        if (free_pages) atomicAdd(&counts[5], free_pages);
+    }
     unsigned long long v[LIVE_N];
     for (int k = 0; k < LIVE_N; ++k) v[k] = 0;
     if (in) {
@@ -942,7 +984,10 @@ __global__ void k_apply_grow(Slot<NW>* slots, const GrowReq* req, uint32_t n, Ba
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Slot<NW>& s = slots[req[i].slot];
-    if (s.pool_blk) pool_give_back(B.pool, s.pool_blk);
+    if (s.pool_blk) {
+        Slot<NW> unused = s;
+        leave_arena(s, unused, B);
+    }
     s.pool_blk = 0;
     s.cap = req[i].cap;
     s.stats_off = req[i].stats_off;
@@ -1546,8 +1591,9 @@ struct Engine {
     uint32_t gatherw_waves = 2048;
     uint32_t gatherw_passes = 0xFFFFFFFFu;  // passes one launch may run; gathers that are not complete then are parked between two picks
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
-    uint32_t pool_low[POOL_CLASSES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // fewest free blocks seen
-    DevBuf<uint32_t> pool_ids;
+    size_t region_bytes = 0;
+    uint32_t region_low_mb = 0xFFFFFFFFu;  // least the region had left: MB never carved + MB in free blocks
+    DevBuf<unsigned long long> pool_bits;
     DevBuf<int> pool_ctr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;  // ev_order: side streams start after the main stream's refills
     double device_ms = 0.0;
@@ -1590,7 +1636,6 @@ struct Engine {
         b.maze = maze.p;
         b.maze_stage = (!per_slot_maze && maze.n > 0 && maze.n <= MAZE_STAGE_BYTES && maze.n % 4 == 0) ? (uint32_t)maze.n : 0u;
         b.L = L;
-        b.cap0 = cap0;
         b.pool = pool;
         return b;
     }
@@ -1603,9 +1648,9 @@ struct Engine {
         return b;
     }
 
-    // `pool_bytes`: device memory to carve into overflow blocks (0 = none: every growth goes through the host)
+    // `tree_bytes`: device memory for the trees (0 = one smallest block per game: every growth goes through the host)
     int setup(int device, uint32_t n_slots, const SearchCfg& c, uint32_t mt, const std::vector<uint8_t>& maze_bytes,
-              uint32_t arena_nodes, bool need_queue, size_t pool_bytes = 0) {
+              uint32_t arena_nodes, bool need_queue, size_t tree_bytes = 0) {
         dev = device;
         S = n_slots;
         cfg = c;
@@ -1641,7 +1686,7 @@ struct Engine {
             if (const char* e = getenv("AR_GW_PASSES"))
                 if (atoi(e) > 0) gatherw_passes = (uint32_t)atoi(e);
         }
-        cap0 = arena_nodes ? arena_nodes : initial_arena_nodes(cfg);
+        cap0 = arena_nodes ? (uint32_t)align_up(arena_nodes, 64) : initial_arena_nodes(cfg);  // (arenas are whole 256-byte units)
         slot_grown.assign(S, nullptr);
         slot_grown_cap.assign(S, 0u);
         HIP_TRY(slots.alloc(S));
@@ -1653,41 +1698,36 @@ struct Engine {
 #endif
         HIP_TRY(scratch.alloc((size_t)S * L.total));
         if ((size_t)S * L.total >= ((size_t)1 << 32)) gather8 = false;  // k_gather8 addresses scratch with 32-bit offsets
-        // overflow pool: 2x / 4x / 8x blocks sharing the budget 55 / 33 / 12 by bytes, at most one per game each
-        size_t pool_off = align_up((size_t)S * arena_bytes(cap0), 256), pool_end = pool_off;
+        // the tree region: pages, a bitmap per zone of 1024 slots; at least a fresh game's pages for every slot
+        size_t region = tree_bytes;
         {
-            const double share[POOL_CLASSES] = {0.55, 0.33, 0.12};
-            uint32_t total_ids = 0;
-            for (int k = 0; k < POOL_CLASSES; ++k) {
-                const size_t blk = arena_bytes(cap0 << (k + 1));
-                size_t n = (size_t)((double)pool_bytes * share[k]) / blk;
-                if (n > S) n = S;
-                if (n >= (1u << 24)) n = (1u << 24) - 1;
-                pool.n[k] = (uint32_t)n;
-                pool.off[k] = (long long)pool_end;
-                pool_end = align_up(pool_end + n * blk, 256);
-                total_ids += (uint32_t)n;
+            pool.page_nodes = arena_nodes ? cap0 : (uint32_t)POOL_PAGE_NODES;  // (test knob: small pages, fresh games on a single one)
+            pool.fresh_pages = arena_nodes ? 1u : (initial_arena_nodes(cfg) + POOL_PAGE_NODES - 1) / POOL_PAGE_NODES;
+            if (pool.fresh_pages > POOL_WORD_PAGES) return fail(AR_E_INVALID, "simulations per move beyond what one run of tree pages holds");
+            cap0 = pool.fresh_pages * pool.page_nodes;
+            pool.page_bytes = arena_bytes(pool.page_nodes);
+            const size_t word_bytes = (size_t)POOL_WORD_PAGES * pool.page_bytes;
+            pool.zones = (S + POOL_ZONE_SLOTS - 1) / POOL_ZONE_SLOTS;
+            {
+                // (every zone holds a fresh arena per slot of a full zone, with room for runs that do not pack a word)
+                const size_t floor_b = (size_t)(S < POOL_ZONE_SLOTS ? S : (uint32_t)POOL_ZONE_SLOTS) * pool.fresh_pages * pool.page_bytes * 5 / 4 + word_bytes;
+                const size_t share = region / pool.zones;
+                const size_t zb = share > floor_b ? share : floor_b;
+                pool.zone_words = (uint32_t)((zb + word_bytes - 1) / word_bytes);
             }
-            if (total_ids > 0) {
-                HIP_TRY(pool_ids.alloc((size_t)total_ids * 2));
-                HIP_TRY(pool_ctr.alloc(2 * POOL_CLASSES));
-                std::vector<uint32_t> ids((size_t)total_ids * 2, 0u);
-                int ctr[2 * POOL_CLASSES];
-                uint32_t at = 0;
-                for (int k = 0; k < POOL_CLASSES; ++k) {
-                    pool.free_ids[k] = pool_ids.p + at;
-                    pool.ret_ids[k] = pool_ids.p + at + pool.n[k];
-                    for (uint32_t i = 0; i < pool.n[k]; ++i) ids[at + i] = i;
-                    at += 2 * pool.n[k];
-                    ctr[k] = (int)pool.n[k];
-                    ctr[POOL_CLASSES + k] = 0;
-                }
-                pool.top = pool_ctr.p;
-                pool.ret_n = (uint32_t*)(pool_ctr.p + POOL_CLASSES);
-                HIP_TRY(hipMemcpy(pool_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(pool_ctr.p, ctr, sizeof ctr, hipMemcpyHostToDevice));
-            }
+            pool.zone_bytes = (unsigned long long)pool.zone_words * word_bytes;
+            region = (size_t)pool.zone_bytes * pool.zones;
+            region_bytes = region;
+            pool.ret_cap = 2 * POOL_ZONE_SLOTS + 64;
+            HIP_TRY(pool_bits.alloc((size_t)pool.zones * pool.zone_words + (size_t)pool.zones * pool.ret_cap));
+            HIP_TRY(hipMemsetAsync(pool_bits.p, 0, 8 * (size_t)pool.zones * pool.zone_words, stream));
+            HIP_TRY(pool_ctr.alloc(pool.zones + 2));
+            HIP_TRY(hipMemsetAsync(pool_ctr.p, 0, sizeof(int) * (pool.zones + 2), stream));
+            pool.bits = pool_bits.p;
+            pool.ret = pool_bits.p + (size_t)pool.zones * pool.zone_words;
+            pool.ret_n = (uint32_t*)pool_ctr.p;
         }
+        const size_t pool_end = region;
         HIP_TRY(arena.alloc(dev, pool_end + 256));
         HIP_TRY(maze.alloc(maze_bytes.size()));
         HIP_TRY(hipMemcpyAsync(maze.p, maze_bytes.data(), maze_bytes.size(), hipMemcpyHostToDevice, stream));
@@ -1785,14 +1825,23 @@ struct Engine {
     double gather_ms = 0.0;
     uint64_t gather_launches = 0;
     bool overlap_advance = true;
+    bool merge_per_group = false;
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
         if (n < 1) n = 1;
         if (n > S) n = S;
         groups.resize(n);
+        // groups of whole pool zones when there are enough games: a group's tree reuse then hands blocks out and takes
+        // them back in its own zones only, and can put returned blocks back on the free stacks at every step
+        merge_per_group = S / n >= POOL_ZONE_SLOTS;
+        auto cut = [&](uint32_t g) {
+            uint32_t at = (uint32_t)((uint64_t)S * g / n);
+            if (merge_per_group && g > 0 && g < n) at = at / POOL_ZONE_SLOTS * POOL_ZONE_SLOTS;
+            return at;
+        };
         for (uint32_t g = 0; g < n; ++g) {
-            groups[g].first = (uint32_t)((uint64_t)S * g / n);
-            groups[g].end = (uint32_t)((uint64_t)S * (g + 1) / n);
+            groups[g].first = cut(g);
+            groups[g].end = cut(g + 1);
             // group 0 runs on the engine's own stream: with two groups that makes four streams (two step streams, two
             // tree-reuse side streams), which is what the runtime maps to hardware queues by default (GPU_MAX_HW_QUEUES
             // = 4); a fifth stream shares a queue with another and the pipeline collapses (measured: 321 M against
@@ -1886,6 +1935,16 @@ struct Engine {
         } else
             hipLaunchKernelGGL(k_backup<NW>, dim3((n + backup_lanes - 1) / backup_lanes), dim3(64), 0, g.stream, slots.p, g.end,
                                cfg, bases(), zig.p, ev, backup_lanes, g.first, phase);
+        // blocks the group's trees left at the last step go back on the free stacks (nothing reads them any more, and
+        // this stream is the only one that pops or returns in the group's zones)
+        if (merge_per_group && pool.bits) {
+            const uint32_t z0 = g.first / POOL_ZONE_SLOTS, z1 = (g.end + POOL_ZONE_SLOTS - 1) / POOL_ZONE_SLOTS;
+            if (side) {
+                HIP_TRY(hipEventRecord(g.backed_up, g.stream));
+                HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
+            }
+            hipLaunchKernelGGL(k_pool_merge, dim3(z1 - z0), dim3(64), 0, side ? g.adv_stream : g.stream, pool, z0, z1 - z0);
+        }
         if (side) {
             HIP_TRY(hipEventRecord(g.backed_up, g.stream));
             HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
@@ -1910,6 +1969,7 @@ struct Engine {
                            zig.p, from_queue ? ev_queue.p : (const EvalOut*)nullptr, lanes, 0u, 0u);
     }
     void launch_advance() {
+        if (pool.bits) hipLaunchKernelGGL(k_pool_merge, dim3(pool.zones), dim3(64), 0, stream, pool, 0u, pool.zones);
         hipLaunchKernelGGL(k_advance<NW>, dim3(S), dim3(64), 0, stream, slots.p, S, bases(), cfg, 0u, 0u, (uint32_t)SLOT_ACTIVE);
     }
     void launch_cancel() { hipLaunchKernelGGL(k_cancel<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, bases()); }
@@ -1958,7 +2018,7 @@ struct Engine {
 
     // after run_steps: status lists on the host. Also accumulates device time.
     int scan(uint32_t out_counts[4]) {
-        if (pool.top) hipLaunchKernelGGL(k_pool_merge, dim3(POOL_CLASSES), dim3(256), 0, stream, pool);
+        if (pool.bits) hipLaunchKernelGGL(k_pool_merge, dim3(pool.zones), dim3(64), 0, stream, pool, 0u, pool.zones);
         HIP_TRY(hipMemsetAsync(counts.p, 0, 32, stream));
         HIP_TRY(hipMemsetAsync(live.p, 0, 8 * LIVE_N, stream));
         hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
@@ -1987,8 +2047,10 @@ struct Engine {
         }
         gather_ev_used = 0;
         for (int i = 0; i < 4; ++i) out_counts[i] = h_counts.p[i];
-        for (int c = 0; c < POOL_CLASSES; ++c)
-            if (pool.n[c] && h_counts.p[5 + c] < pool_low[c]) pool_low[c] = h_counts.p[5 + c];
+        {
+            const uint32_t left_mb = (uint32_t)(((unsigned long long)h_counts.p[5] * pool.page_bytes) >> 20);
+            if (left_mb < region_low_mb) region_low_mb = left_mb;
+        }
         return AR_OK;
     }
 
@@ -2388,16 +2450,19 @@ struct SelfPlaySession : SessionBase {
             // its evaluator (AR_UNIFORM=fused | queue; results are identical)
             eng.uniform_queue = net == nullptr && default_uniform_queue(S);
             if (const char* e = getenv("AR_UNIFORM")) eng.uniform_queue = net == nullptr && std::string(e) == "queue";
-            const size_t per_game = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg)) +
-                                    Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr || eng.uniform_queue);
-            const size_t budget = free_b / 10 * 4;  // first arenas take at most 40%: trees that outgrow them need the rest
-            if ((size_t)S * per_game > budget) S = (uint32_t)(budget / per_game);
+            // device memory per resident game: its scratch and queue share, and its tree. A tree lives in a block of the
+            // smallest size class (4/3 apart) that holds it plus one full search; averaged over a game's life that is about
+            // twice a fresh game's block at the tuned 7x7 configuration (measured: mean tree top 2150 nodes at 1897
+            // simulations per move), which is what the resident count is sized by -- games beyond what the region can
+            // serve would only wait for blocks.
+            const size_t fresh = arena_bytes(arena_nodes ? arena_nodes : initial_arena_nodes(cfg));
+            const size_t overhead = Engine<NW>::per_game_overhead(cfg, p.max_turns, net != nullptr || eng.uniform_queue);
+            const size_t reserve = (size_t)4 << 30;  // the evaluator's buffers, arenas beyond the largest class (host-allocated)
+            const size_t usable = free_b > reserve ? free_b - reserve : 0;
+            const size_t per_game = 2 * fresh + overhead;
+            if ((size_t)S * per_game > usable) S = (uint32_t)(usable / per_game);
             if (S == 0) return fail(AR_E_NOMEM, "not enough device memory for a single game arena");
-            // the overflow pool gets what is left, minus a reserve for the evaluator's buffers and the
-            // (rare) arenas beyond the largest pool class, which the host allocates one by one
-            const size_t reserve = (size_t)4 << 30;
-            const size_t used = (size_t)S * per_game;
-            pool_bytes = free_b > used + reserve ? (free_b - used - reserve) / 100 * 85 : 0;
+            pool_bytes = (usable - (size_t)S * overhead) / 100 * 95;
         }
 
         // AR_TIMING=1 prints where the host wall time of this run went (stderr)
@@ -2415,7 +2480,9 @@ struct SelfPlaySession : SessionBase {
             while (e < want && e < (1ULL << 26)) e <<= 1;
             eng.cache_entries = e;
         }
-        if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: every growth goes through the host path
+        if (getenv("AR_NO_POOL")) pool_bytes = 0;  // test knob: one smallest block per game, every growth goes through the host path
+        if (const char* e = getenv("AR_TREE_GB"))  // test knob: a small tree region (games wait for blocks, trees move between classes)
+            if (atof(e) > 0.0) pool_bytes = (size_t)(atof(e) * 1073741824.0);
         eng.per_slot_maze = gen_maze;
         eng.maze_stride = (uint32_t)hw * 4u;
         {
@@ -2643,12 +2710,11 @@ struct SelfPlaySession : SessionBase {
         if (timing)
             fprintf(stderr,
                     "[ar timing] games=%llu resident=%u wall=%.3fs device=%.3fs | setup %.3f first-fill %.3f launch %.3f "
-                    "scan-wait %.3f grow %.3f (%llu) drain %.3f records %.3f refill %.3f | pool blocks %u/%u/%u, fewest "
-                    "free %u/%u/%u\n",
+                    "scan-wait %.3f grow %.3f (%llu) drain %.3f records %.3f refill %.3f | tree region %.1f GB, least left "
+                    "%.1f GB\n",
                     (unsigned long long)finished, S, o.elapsed_secs, o.device_secs, tm[0], tm[1], tm[2], tm[3], tm[4],
-                    (unsigned long long)eng.grows, tm[5], tm[6], tm[7], eng.pool.n[0], eng.pool.n[1], eng.pool.n[2],
-                    eng.pool.n[0] ? eng.pool_low[0] : 0u, eng.pool.n[1] ? eng.pool_low[1] : 0u,
-                    eng.pool.n[2] ? eng.pool_low[2] : 0u);
+                    (unsigned long long)eng.grows, tm[5], tm[6], tm[7], (double)eng.region_bytes / 1073741824.0,
+                    eng.region_low_mb == 0xFFFFFFFFu ? -1.0 : (double)eng.region_low_mb / 1024.0);
         if (total) *total = o;
         return rc;
     }

@@ -1324,7 +1324,7 @@ AR_HD void advance_tree_scalar(Slot<NW>& s, const Mem<NW>& m) {
 
 // Start a game in a slot (selfplay.rs:526-535). The caller has filled board, st, rng and the arena.
 template <int NW>
-AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
+AR_HD void start_game_header(Slot<NW>& s, const SearchCfg& cfg) {
     s.n_pos = 0;
     s.t_sims = s.t_nn = s.t_term = s.t_coll = 0;
     s.nv_gather = s.nv_backup = s.new_nodes = 0;
@@ -1336,6 +1336,10 @@ AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
     s.gather_pending = 0;
     s.g_rounds = 0;
     s.remaining = cfg.n_sims;
+}
+template <int NW>
+AR_HD void start_game(Slot<NW>& s, const Mem<NW>& m, const SearchCfg& cfg) {
+    start_game_header(s, cfg);
     make_root(s, m);
     if (!s.single_search && st_over(s.board, s.st)) s.status = SLOT_DONE;  // while !check_game_over()
     else s.status = SLOT_ACTIVE;

@@ -73,11 +73,11 @@ inline uint32_t next_pow2(uint32_t v) {
     while (p < v) p <<= 1;
     return p;
 }
-// first arena of a game: the kept subtree plus one search fits with room to spare; bigger trees
-// stall once and are moved to a doubled arena
+// arena of a fresh game (the smallest size class): the root plus one full search, as k_advance sizes it (arena_need),
+// in whole groups of 64 nodes (an arena is then a whole number of 256-byte units)
 inline uint32_t initial_arena_nodes(const SearchCfg& cfg) {
-    uint32_t want = 2 * (cfg.n_sims + 2 * cfg.batch_size) + 64;
-    uint32_t p = next_pow2(want);
+    const uint32_t want = 1 + cfg.n_sims + 2 * cfg.batch_size + 64;
+    const uint32_t p = (want + 63) / 64 * 64;
     return p < 256 ? 256 : p;
 }
 // bytes of one arena of `cap` nodes: [node records | fwd]
