@@ -85,6 +85,14 @@ class ArSelfPlayStats(C.Structure):
     ]
 
 
+class ArSessionInfo(C.Structure):
+    _fields_ = [
+        ("resident_games", C.c_uint32), ("groups", C.c_uint32), ("gather_kind", C.c_uint32), ("gather_pass_limit", C.c_uint32),
+        ("tree_region_bytes", C.c_uint64), ("host_grown_arenas", C.c_uint64), ("idle_slots", C.c_uint32),
+        ("tree_pages_per_game", C.c_float),
+    ]
+
+
 class ArProgress(C.Structure):
     _fields_ = [
         ("games_completed", C.c_uint32), ("positions_completed", C.c_uint64),
@@ -140,6 +148,7 @@ EXPORTS = {
                                    C.POINTER(C.c_void_p)]),
     "ar_selfplay_step": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(ArSelfPlayStats), C.POINTER(C.c_int)]),
     "ar_selfplay_close": (C.c_int, [C.c_void_p, C.POINTER(ArSelfPlayStats)]),
+    "ar_selfplay_info": (C.c_int, [C.c_void_p, C.POINTER(ArSessionInfo)]),
     "ar_write_bundle": (C.c_int, [C.POINTER(ArGameRecordView), C.c_uint32, C.c_char_p]),
 }
 
@@ -153,7 +162,15 @@ def load() -> C.CDLL:
         return _lib
     # one hardware queue per stream of the step pipeline (see alpharat_hip.hip "hardware queues"): effective when the
     # HIP runtime has not been initialised in this process yet
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # -- so it is only set when nothing can have brought the runtime up before (torch with an initialised device has)
+    import sys
+
+    torch = sys.modules.get("torch")
+    runtime_up = bool(torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized())
+    if runtime_up:
+        os.environ.setdefault("AR_HW_QUEUES_UNKNOWN", "1")  # the library then keeps one group of games (no extra streams)
+    else:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

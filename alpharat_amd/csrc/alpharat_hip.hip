@@ -38,17 +38,27 @@ using namespace ar;
 // ------------------------------------------------------------------------------------------------
 // hardware queues
 // ------------------------------------------------------------------------------------------------
-// The step pipeline of a large run keeps five streams busy at once (two groups of games x {walk + evaluator, tree
-// reuse} + the engine's own). The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default:
+// The step pipeline of a large run keeps four streams busy at once (two groups of games x {walk + evaluator, tree
+// reuse}; group 0 runs on the engine's own stream). The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default:
 // streams that share a queue serialise, and the pipeline runs 1.1-1.7x slower than with one queue per stream
 // (measured). The variable is read when the runtime initialises, so it is set when this
 // library is loaded -- unless the host has chosen a value itself. A process that brought the runtime up earlier
 // (e.g. torch imported first) has to export it itself: bench.py does.
-__attribute__((constructor)) static void ar_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-static int hw_queues() {
+// What is known about the queues is what the variable said when this library was loaded: a value set later (by this
+// constructor, or by anyone) does not reach a runtime that is already up. AR_HW_QUEUES_UNKNOWN=1 (set by
+// alpharat_amd/_lib.py when torch has initialised a device before the library is loaded) says exactly that.
+static int g_hw_queues_at_load = 0;
+__attribute__((constructor)) static void ar_more_hw_queues() {
     const char* e = getenv("GPU_MAX_HW_QUEUES");
-    return e ? atoi(e) : 4;
+    if (getenv("AR_HW_QUEUES_UNKNOWN")) {
+        g_hw_queues_at_load = e ? atoi(e) : 4;  // whatever the runtime came up with: not ours to change now
+        return;
+    }
+    if (!e) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    e = getenv("GPU_MAX_HW_QUEUES");
+    g_hw_queues_at_load = e ? atoi(e) : 4;
 }
+static int hw_queues() { return g_hw_queues_at_load; }
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -143,7 +153,8 @@ __device__ inline uint32_t pool_claim(const ArenaPool& P, uint32_t slot, uint32_
     const uint32_t zone = slot / POOL_ZONE_SLOTS;
     unsigned long long* words = P.bits + (size_t)zone * P.zone_words;
     const unsigned long long run = n >= 64 ? ~0ULL : ((1ULL << n) - 1ULL);
-    uint32_t w = (slot * 7u) % P.zone_words;
+    // (the start words cover the low end of the zone only: a zone that is far from full keeps its trees close together)
+    uint32_t w = (slot * 7u) % (P.zone_words < 96u ? P.zone_words : 96u);
     for (uint32_t tries = 0; tries < P.zone_words; ++tries, w = w + 1 == P.zone_words ? 0 : w + 1) {
         for (int again = 0; again < 4; ++again) {  // (a few retries on a word others are claiming from too)
             const unsigned long long taken = __hip_atomic_load(&words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -909,6 +920,11 @@ __global__ void k_scan(const Slot<NW>* slots, uint32_t n_slots, uint32_t* counts
             v[7] = s.new_nodes;
             v[8] = 1;
         }
+        // what a game that has been running for a while holds in tree pages (the host sizes the resident set by it)
+        if (live != nullptr && st != SLOT_EMPTY && st != SLOT_DONE && s.pool_blk != 0 && s.n_pos >= 4) {
+            atomicAdd(&live[12], (unsigned long long)s.pool_blk);
+            atomicAdd(&live[13], 1ULL);
+        }
     }
     if (live == nullptr) return;
     for (int k = 0; k < LIVE_N; ++k) {  // one atomic per wavefront and counter
@@ -949,7 +965,16 @@ __global__ void k_pack_done(Slot<NW>* slots, const uint32_t* done_list, uint32_t
     uint32_t* dst = (uint32_t*)(staging + (size_t)d * max_turns);
     for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
     __syncthreads();
-    if (threadIdx.x == 0) s.status = SLOT_EMPTY;
+    if (threadIdx.x == 0) {
+        // the finished game's tree pages go back now (the slot may stay empty for a while: the host admits new games by
+        // what the zone has free); an arena from the host is flagged for release
+        Slot<NW> unused = s;
+        leave_arena(s, unused, B);
+        if (unused.release_grown) s.release_grown = 1;
+        s.cap = 0;
+        s.pool_blk = 0;
+        s.status = SLOT_EMPTY;
+    }
 }
 
 // arena growth: what a stalled slot reports, and its new home once the host has copied the nodes
@@ -1589,7 +1614,11 @@ struct Engine {
     // network path: the gather as a work queue over tree levels (k_gatherw, dev_gatherw.h); a persistent grid of `gatherw_waves`
     bool gatherw = false;
     uint32_t gatherw_waves = 2048;
-    uint32_t gatherw_passes = 0xFFFFFFFFu;  // passes one launch may run; gathers that are not complete then are parked between two picks
+    // passes one launch may run; gathers that are not complete then are parked between two picks and go on in the next
+    // launch. A game needs 50 passes in the median, 110 at the 90th and 160 at the 99th percentile, a few need 300+
+    // (profiles/r03_gw_stats.txt): without a limit every launch lasts as long as its slowest game. Measured at 131072
+    // resident games: 64 / 80 / 96 / 128 / 192 passes -> 638 / 646 / 643 / 615 / 598 M simulations/s.
+    uint32_t gatherw_passes = 96;
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     size_t region_bytes = 0;
     uint32_t region_low_mb = 0xFFFFFFFFu;  // least the region had left: MB never carved + MB in free blocks
@@ -1615,6 +1644,7 @@ struct Engine {
             }
             if (g.done) hipEventDestroy(g.done);
             if (g.backed_up) hipEventDestroy(g.backed_up);
+            if (g.gathered) hipEventDestroy(g.gathered);
             if (g.adv_ev[0]) hipEventDestroy(g.adv_ev[0]);
             if (g.adv_ev[1]) hipEventDestroy(g.adv_ev[1]);
             if (g.adv_done) hipEventDestroy(g.adv_done);
@@ -1680,11 +1710,13 @@ struct Engine {
         if (gatherw) {
             int cus = 0;
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            gatherw_waves = (uint32_t)(cus > 0 ? cus : 256) * 8u;  // two wavefronts per SIMD, 32 (16 on boards above 64 cells) games each
+            // two wavefronts per SIMD (212 registers each), 32 (16 on boards above 64 cells) games each -- less one per CU: the
+            // grid is persistent, and the other group's small kernels (k_finish, k_backup: 130-220 registers) then find
+            // a SIMD with room instead of waiting for a gather wavefront to end (655 vs 643 M simulations/s)
+            gatherw_waves = (uint32_t)(cus > 0 ? cus : 256) * 7u;
             if (const char* e = getenv("AR_GW_WAVES"))
                 if (atoi(e) > 0) gatherw_waves = (uint32_t)atoi(e);
-            if (const char* e = getenv("AR_GW_PASSES"))
-                if (atoi(e) > 0) gatherw_passes = (uint32_t)atoi(e);
+            if (const char* e = getenv("AR_GW_PASSES")) gatherw_passes = atoi(e) > 0 ? (uint32_t)atoi(e) : 0xFFFFFFFFu;  // 0: no limit
         }
         cap0 = arena_nodes ? (uint32_t)align_up(arena_nodes, 64) : initial_arena_nodes(cfg);  // (arenas are whole 256-byte units)
         slot_grown.assign(S, nullptr);
@@ -1816,6 +1848,7 @@ struct Engine {
     struct Group {
         hipStream_t stream = nullptr, adv_stream = nullptr;
         hipEvent_t done = nullptr, backed_up = nullptr, adv_done = nullptr, adv_ev[2] = {nullptr, nullptr};
+        hipEvent_t gathered = nullptr;  // the group's last gather launch is complete
         uint32_t first = 0, end = 0;  // slots [first, end)
         uint64_t step = 0;
     };
@@ -1826,6 +1859,7 @@ struct Engine {
     uint64_t gather_launches = 0;
     bool overlap_advance = true;
     bool merge_per_group = false;
+    bool stagger_gathers = false;
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
         if (n < 1) n = 1;
@@ -1846,6 +1880,7 @@ struct Engine {
             // tree-reuse side streams), which is what the runtime maps to hardware queues by default (GPU_MAX_HW_QUEUES
             // = 4); a fifth stream shares a queue with another and the pipeline collapses (measured: 321 M against
             // 565 M simulations/s)
+            HIP_TRY(hipEventCreateWithFlags(&groups[g].gathered, hipEventDisableTiming));
             if (g > 0) {
                 HIP_TRY(hipStreamCreateWithFlags(&groups[g].stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].done, hipEventDisableTiming));
@@ -1872,6 +1907,13 @@ struct Engine {
         EvalOut* ev = ev_queue.p + (size_t)g.first * cfg.batch_size;
         uint32_t* qc = queue_count.p + gi;
         HIP_TRY(hipMemsetAsync(qc, 0, 4, g.stream));
+        // (AR_STAGGER=1, off by default) One gather at a time: a group's tree walk starts when the previous group's (in launch
+        // order) has ended. Left to themselves the groups drift into step -- both walk, then both evaluate (kernel trace,
+        // profiles/r03_timeline_131k.txt) -- so stages do not overlap across groups. Held apart they do not overlap either:
+        // the persistent gather fills every SIMD's registers (2 x 212 of 512) and the evaluator's wavefronts (141) wait for
+        // it to end: 588 vs 643 M simulations/s, also with half the gather wavefronts (570 M).
+        if (stagger_gathers && groups.size() > 1)
+            HIP_TRY(hipStreamWaitEvent(g.stream, groups[(gi + groups.size() - 1) % groups.size()].gathered, 0));
         const bool timed_launch = true;  // every group's gather launch is timed on its own stream
         if (timed_launch) {
             while (gather_ev.size() < gather_ev_used + 2) {
@@ -1904,6 +1946,7 @@ struct Engine {
             HIP_TRY(hipEventRecord(gather_ev[gather_ev_used + 1], g.stream));
             gather_ev_used += 2;
         }
+        HIP_TRY(hipEventRecord(g.gathered, g.stream));
         if (gatherw)
             hipLaunchKernelGGL(k_pack_leaves<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, bases(), g.first, q, qc);
         const uint32_t n_max = (uint32_t)((size_t)n * cfg.batch_size);
@@ -2020,12 +2063,12 @@ struct Engine {
     int scan(uint32_t out_counts[4]) {
         if (pool.bits) hipLaunchKernelGGL(k_pool_merge, dim3(pool.zones), dim3(64), 0, stream, pool, 0u, pool.zones);
         HIP_TRY(hipMemsetAsync(counts.p, 0, 32, stream));
-        HIP_TRY(hipMemsetAsync(live.p, 0, 8 * LIVE_N, stream));
+        HIP_TRY(hipMemsetAsync(live.p, 0, 8 * 16, stream));
         hipLaunchKernelGGL(k_scan<NW>, dim3(grid(S)), dim3(64), 0, stream, slots.p, S, counts.p, done_list.p,
                            stall_list.p, release_list.p, pool, live.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_counts.p, counts.p, 32, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(h_live.p, live.p, 8 * LIVE_N, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(h_live.p, live.p, 8 * 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (const uint32_t n_rel = h_counts.p[4]) {  // slots that moved back to their pool share
             HIP_TRY(hipMemcpyAsync(h_release.p, release_list.p, 4 * n_rel, hipMemcpyDeviceToHost, stream));
@@ -2314,6 +2357,7 @@ static uint32_t default_gather_rounds(const SearchCfg&) { return 0xFFFFFFFFu; }
 // lives for one call only; the slicing is an extension.
 struct SessionBase {
     virtual ~SessionBase() {}
+    virtual void info(ArSessionInfo* out) const = 0;
     virtual int step(uint32_t batch_steps, ArSelfPlayStats* window, int* finished_out) = 0;
     virtual int close(ArSelfPlayStats* total) = 0;
 };
@@ -2344,6 +2388,16 @@ struct SelfPlaySession : SessionBase {
     bool timing = false, failed = false;
     double tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+    void info(ArSessionInfo* out) const override {
+        out->resident_games = S;
+        out->groups = (uint32_t)(eng.groups.empty() ? 1 : eng.groups.size());
+        out->gather_kind = !eng.use_queue() ? 3u : eng.gatherw ? 2u : eng.gather8 ? 1u : 0u;
+        out->gather_pass_limit = eng.gatherw ? eng.gatherw_passes : 0xFFFFFFFFu;
+        out->tree_region_bytes = eng.region_bytes;
+        out->host_grown_arenas = eng.grows;
+        out->idle_slots = (uint32_t)idle_slots.size();
+        out->tree_pages_per_game = (float)pages_per_game;
+    }
     ~SelfPlaySession() override {
         if (to_disk) writer.finish();
         if (eng.stream) hipStreamSynchronize(eng.stream);
@@ -2373,11 +2427,40 @@ struct SelfPlaySession : SessionBase {
     bool supply_left() const { return unbounded || next_game < p.num_games; }
     bool all_finished() const { return !unbounded && finished >= p.num_games; }
 
+    // How many games are resident is bounded by what their trees need, and that depends on the run (the network's priors
+    // decide how much of a tree survives a move): a slot is only given a new game while its zone of the tree region would
+    // stay under 88 % with every resident game at the size games of this run have after a few moves (measured by k_scan;
+    // four fresh arenas per game until there is a measurement). Slots that have to wait are tried again at every visit.
+    // Without this, 131072 games with a network that keeps big subtrees fill the region before the first generation has
+    // finished, nothing can grow any more, and the run crawls (24 M instead of 370 M simulations/s, measured).
+    std::vector<uint8_t> slot_busy;
+    std::vector<uint32_t> zone_busy, idle_slots;
+    double pages_per_game = 0.0;
+    bool admit(uint32_t slot) const {
+        const uint32_t z = slot / POOL_ZONE_SLOTS;
+        const double zone_pages = (double)eng.pool.zone_words * POOL_WORD_PAGES;
+        return ((double)zone_busy[z] + 1.0) * pages_per_game <= 0.88 * zone_pages || zone_busy[z] == 0;
+    }
+    void leave_slot(uint32_t slot) {
+        if (slot < slot_busy.size() && slot_busy[slot]) {
+            slot_busy[slot] = 0;
+            zone_busy[slot / POOL_ZONE_SLOTS] -= 1;
+        }
+    }
     int refill(const std::vector<uint32_t>& free_slots) {
         std::vector<GameInit<NW>> inits;
         std::vector<uint8_t> mazes;
-        for (uint32_t sl : free_slots) {
+        std::vector<uint32_t> candidates;
+        candidates.swap(idle_slots);
+        candidates.insert(candidates.end(), free_slots.begin(), free_slots.end());
+        for (uint32_t sl : candidates) {
             if (!supply_left()) break;
+            if (!admit(sl)) {
+                idle_slots.push_back(sl);
+                continue;
+            }
+            slot_busy[sl] = 1;
+            zone_busy[sl / POOL_ZONE_SLOTS] += 1;
             const uint32_t index = p.first_game_index + (uint32_t)next_game;  // wraps in an unbounded session
             HostGame g;
             if (!make_game(index, g)) return fail(AR_E_INVALID, err);
@@ -2503,6 +2586,7 @@ struct SelfPlaySession : SessionBase {
                 if (atoi(e) >= 1 && atoi(e) <= 64) ng = (uint32_t)atoi(e);
             if (eng.cache_entries) ng = 1;  // one probe/fill pair in flight at a time: a reader never overlaps an eviction
             if (getenv("AR_NO_ADVANCE_OVERLAP")) eng.overlap_advance = false;
+            if (getenv("AR_STAGGER")) eng.stagger_gathers = true;
             if (int rc = eng.make_groups(ng)) return rc;
         }
         if (const char* e = getenv("AR_LANES_PER_WAVE"))
@@ -2512,6 +2596,9 @@ struct SelfPlaySession : SessionBase {
         if (eng.gather_rounds != 0xFFFFFFFFu) eng.gather8 = eng.gatherw = false;  // the round limit parks the walk: lane kernel only
         if (to_disk) writer.start();
         slot_game.resize(S);
+        slot_busy.assign(S, 0);
+        zone_busy.assign(eng.pool.zones, 0u);
+        pages_per_game = 4.0 * (double)eng.pool.fresh_pages;
         t0 = std::chrono::steady_clock::now();
         tp = t0;
         std::vector<uint32_t> all(S);
@@ -2599,6 +2686,8 @@ struct SelfPlaySession : SessionBase {
 
     int step(uint32_t batch_steps, ArSelfPlayStats* window, int* finished_out) override {
         if (failed) return fail(AR_E_INVALID, "the session has failed earlier; close it");
+        if (unbounded && batch_steps == 0xFFFFFFFFu)
+            return fail(AR_E_INVALID, "a session with an endless supply of games cannot be run to its end: pass a number of batch steps");
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(now() - a).count(); };
         const auto w0 = now();
@@ -2622,6 +2711,8 @@ struct SelfPlaySession : SessionBase {
             uint32_t c[4];
             if ((rc = eng.scan(c)) != AR_OK) break;
             for (int k = 0; k < LIVE_N; ++k) live[k] = eng.h_live.p[k];
+            if (eng.h_live.p[13] >= 256)  // tree pages of a game that has played a few moves, in this run
+                pages_per_game = std::max((double)eng.pool.fresh_pages, 1.1 * (double)eng.h_live.p[12] / (double)eng.h_live.p[13]);
             tm[3] += since(tp);
             tp = now();
             if (c[3] != 0) {
@@ -2643,12 +2734,15 @@ struct SelfPlaySession : SessionBase {
                     if (di.n_pos < win_min) win_min = di.n_pos;
                     if (di.n_pos > win_max) win_max = di.n_pos;
                     free_slots.push_back(di.slot);
+                    leave_slot(di.slot);
                     ++finished;
                 }
                 tm[6] += since(tp);
                 tp = now();
                 if ((rc = refill(free_slots)) != AR_OK) break;
                 tm[7] += since(tp);
+            } else if (!idle_slots.empty() && supply_left()) {
+                if ((rc = refill(std::vector<uint32_t>())) != AR_OK) break;  // (slots that waited for room in their zone)
             }
             if (c[0] == 0 && c[1] == 0 && c[2] == 0 && !all_finished() && !supply_left()) {
                 rc = fail(AR_E_DEVICE, "self-play stalled: no active games left but not all games finished");
@@ -3072,6 +3166,12 @@ int ar_selfplay_open(const ArSelfPlayParams* p, ArProgress* progress, ArGameSink
 int ar_selfplay_step(ArSelfPlaySession* s, uint32_t batch_steps, ArSelfPlayStats* window, int* finished) {
     if (!s || !s->impl) return fail(AR_E_INVALID, "null session");
     return s->impl->step(batch_steps, window, finished);
+}
+
+int ar_selfplay_info(const ArSelfPlaySession* s, ArSessionInfo* out) {
+    if (!s || !s->impl || !out) return fail(AR_E_INVALID, "null argument");
+    s->impl->info(out);
+    return AR_OK;
 }
 
 int ar_selfplay_close(ArSelfPlaySession* s, ArSelfPlayStats* total) {

@@ -142,7 +142,9 @@ def _resolve_weights(weights_path, onnx_model_path):
     if weights_path is None and onnx_model_path is not None:
         p = Path(onnx_model_path)
         cand = p if p.suffix == ".arnet" else p.with_suffix(".arnet")
-        if not cand.exists() and p.with_suffix(".pt").exists():
+        if p.with_suffix(".pt").exists():
+            # the trainer overwrites the checkpoint in place: checkpoint_to_blob rewrites the blob when the checkpoint
+            # is newer and is a cheap cache hit otherwise (a bare blob is only trusted when no checkpoint sits next to it)
             from .weights import checkpoint_to_blob
 
             cand = checkpoint_to_blob(p.with_suffix(".pt"))
@@ -243,6 +245,7 @@ class SelfPlaySession:
                         concurrent_games=0, device_index=None)
         defaults.update(kw)
         defaults["weights_path"] = _resolve_weights(defaults["weights_path"], onnx_model_path)
+        self._unbounded = int(defaults["num_games"]) >= UNBOUNDED
         p = _params(**defaults)
         self._sink = _lib.ArGameSink()
         if on_game is not None:
@@ -264,7 +267,18 @@ class SelfPlaySession:
         return SelfPlayStats(out)
 
     def run_to_end(self) -> SelfPlayStats:
+        if self._unbounded:
+            raise ValueError("a session with an endless supply of games (num_games=UNBOUNDED) has no end: use step(n)")
         return self.step(UNBOUNDED)
+
+    def info(self) -> dict:
+        """What the library chose: resident games actually on the device (bounded by the memory the trees need), groups,
+        gather kernel (0 lane, 1 octet, 2 work queue, 3 fused uniform), pass limit per gather launch, tree region bytes."""
+        if not self._h:
+            raise RuntimeError("session is closed")
+        out = _lib.ArSessionInfo()
+        _lib.check(_lib.load().ar_selfplay_info(self._h, C.byref(out)))
+        return {k: (float(getattr(out, k)) if k == "tree_pages_per_game" else int(getattr(out, k))) for k, _ in out._fields_}
 
     def close(self) -> SelfPlayStats | None:
         if not self._h:

@@ -131,7 +131,7 @@ def weights_for(evaluator: str, rank: int) -> str | None:
     return str(ROOT / "tests" / "golden" / "nets" / f"{name}.arnet")
 
 
-def cpu_baseline(blob: str | None, evaluator: str, max_secs: float) -> dict:
+def cpu_baseline(blob: str | None, evaluator: str, max_secs: float, threads: int | None = None) -> dict:
     """The oracle's self-play loop (the reference's worker structure: OS threads claiming games from an atomic
     counter, 16 games per thread like bench_selfplay.rs:213) timed on this box's host cores over a BOUNDED
     sample of the same workload: no thread claims a new game after `max_secs`. value = sum over threads of
@@ -140,29 +140,56 @@ def cpu_baseline(blob: str | None, evaluator: str, max_secs: float) -> dict:
 
     search, sims, batch, _ = WORKLOADS[evaluator]
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    if threads is None:
+        threads = cores  # every hardware thread of the box
     cfg = O.make_config(**search)
     net = O.Net(blob) if blob else None
     games = 16 * threads
     r = O.selfplay_bench(GAME["width"], GAME["height"], GAME["cheese_count"], GAME["max_turns"], games, cfg, sims, batch,
                          threads, backend=2 if net else 0, net=net, max_secs=max_secs)
     return {
-        "value": r["thread_rate_sum"], "unit": "simulations/s", "cores": threads, "kind": "port",
+        # simulations of the sample / its wall time (the ragged end counts against the CPU; the sum of per-thread rates,
+        # which leaves it out, rides along)
+        "value": r["simulations"] / r["elapsed_secs"], "thread_rate_sum": r["thread_rate_sum"], "unit": "simulations/s",
+        "cores": threads, "kind": "port", "build": "g++ -O3 -march=native (oracle/Makefile)",
         "sample": f"{r['games']} games of the same workload finished by {threads} threads claiming from a queue of "
-                  f"{games} until {max_secs:.0f} s had passed ({r['positions']} positions, {r['elapsed_secs']:.1f} s wall); "
-                  "sum of per-thread rates",
+                  f"{games} until {max_secs:.0f} s had passed ({r['positions']} positions, {r['elapsed_secs']:.1f} s wall)",
         "wall_rate": r["simulations"] / r["elapsed_secs"],
         "games_per_sec": r["games"] / r["elapsed_secs"],
         "descents_per_sec": (r["nn_evals"] + r["terminals"]) / r["elapsed_secs"],
     }
 
 
+def under_profiler() -> str | None:
+    """rocprofv3 (and friends) preload a tool library into the process; legs that open a second session are skipped
+    under it (round 2 lost a --pmc pass inside the HIP runtime in exactly such a leg)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in pre or "roctracer" in pre or "rocprofiler" in pre:
+        return "LD_PRELOAD=" + pre
+    for k in os.environ:
+        if k.startswith(("ROCPROF", "ROCPROFILER_", "ROCP_")):
+            return k
+    return None
+
+
 def full_launch_leg(evaluator: str, resident: int, batch_steps: int, device_index: int) -> dict:
-    """The extra leg (its own process, `--full-launch-child`): the same workload with the games as ONE group."""
+    """The extra leg: the same workload with the games as ONE group, i.e. one gather launch over all resident games per
+    batch step. Runs in this process, after the timed session is closed and its device memory released (the group
+    count is a per-session choice the library reads from AR_GROUPS when a session opens)."""
     from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession
 
     search, sims, batch, _ = WORKLOADS[evaluator]
     weights = weights_for(evaluator, 0)
+    os.environ["AR_GROUPS"] = "1"
+    try:
+        return _full_launch_session(evaluator, resident, batch_steps, device_index, search, sims, batch, weights)
+    finally:
+        del os.environ["AR_GROUPS"]
+
+
+def _full_launch_session(evaluator, resident, batch_steps, device_index, search, sims, batch, weights) -> dict:
+    from alpharat_amd.sampling import UNBOUNDED, SelfPlaySession
+
     with SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
                          weights_path=weights, seed=0, first_game_index=1 << 27, concurrent_games=resident,
                          device_index=device_index, **search) as s1:
@@ -176,7 +203,7 @@ def full_launch_leg(evaluator: str, resident: int, batch_steps: int, device_inde
     l1 = max(w1.gather_launches, 1)
     a1 = b1 / l1 / max(w1.gather_secs / l1, 1e-12) / 1e9
     return {"what": "same workload, AR_GROUPS=1: one gather launch over all resident games per batch step (2 timed steps "
-                    "after 4 warm-up steps of a fresh session, in a child process)",
+                    "after 4 warm-up steps of a fresh session in this process, after the timed session was closed)",
             "achieved": a1, "frac": a1 / HBM_PEAK_GBS, "avg_launch_ms": w1.gather_secs / l1 * 1e3,
             "algorithmic_bytes_per_launch": b1 / l1, "simulations_per_sec": w1.total_simulations / dt1,
             "avg_step_ms": w1.device_secs / max(w1.steps, 1) * 1e3}
@@ -191,7 +218,8 @@ def main() -> int:
                     help="passes of the hot path (gather -> evaluate -> backup) over all resident games per step "
                          "(default: 1024 for mlp / uniform, 128 for symmetric, 64 for cnn)")
     ap.add_argument("--resident", type=int, default=0,
-                    help="games resident on each GPU (default: 65536; 16384 for cnn)")
+                    help="games resident on each GPU (default: 131072; 16384 for cnn); the library may choose fewer "
+                         "(device memory), the line reports what it used")
     ap.add_argument("--evaluator", choices=sorted(WORKLOADS), default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-secs", type=float, default=15.0, help="bound of the CPU baseline sample")
@@ -199,13 +227,12 @@ def main() -> int:
                     help="skip the extra leg that times the gather kernel launched over all resident games at once")
     ap.add_argument("--deadline", type=float, default=480.0,
                     help="seconds after process start at which the timed loop stops early and reports the steps done")
-    ap.add_argument("--full-launch-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--record", action="store_true",
+                    help="also build every finished game's record on the host and write the bundles (the reference's "
+                         "recording path) inside the timed region: a sink callback + output_dir on a tmpfs")
+    ap.add_argument("--cpu-sweep", action="store_true",
+                    help="CPU baseline at 1, 8, 32, 64 and all threads (bench_selfplay.rs:213-224) instead of one count")
     args = ap.parse_args()
-
-    if args.full_launch_child:  # (the parent passes --evaluator / --resident / --batch-steps resolved)
-        print(json.dumps(full_launch_leg(args.evaluator, args.resident, args.batch_steps, int(os.environ.get("LOCAL_RANK", "0")))),
-              flush=True)
-        return 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -245,7 +272,7 @@ def main() -> int:
     if args.batch_steps <= 0:
         args.batch_steps = {"symmetric": 128, "cnn": 64}.get(args.evaluator, 1024)
     if args.resident <= 0:
-        args.resident = 16384 if args.evaluator == "cnn" else 65536
+        args.resident = 16384 if args.evaluator == "cnn" else 131072
     weights = weights_for(args.evaluator, rank)
     if dist is not None:
         dist.barrier()
@@ -261,9 +288,18 @@ def main() -> int:
             dist.barrier()
 
     # game ids are global and disjoint across ranks: rank r plays r * 2^28, r * 2^28 + 1, ... (weak scaling)
-    session = SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch, output_dir=None,
+    rec_dir = None
+    rec_games = [0]
+    extra = {}
+    if args.record:
+        import tempfile
+
+        rec_dir = tempfile.mkdtemp(prefix=f"ar_bench_rec_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        extra = dict(output_dir=rec_dir, on_game=lambda g: rec_games.__setitem__(0, rec_games[0] + 1))
+    session = SelfPlaySession(**GAME, num_games=UNBOUNDED, simulations=sims, batch_size=batch,
                               weights_path=weights, seed=0, first_game_index=rank << 28, concurrent_games=args.resident,
-                              device_index=local_rank, **search)
+                              device_index=local_rank, **{"output_dir": None, **extra}, **search)
+    info = session.info()
     t_open = time.perf_counter() - T_START
     for _ in range(args.warmup):
         session.step(args.batch_steps)
@@ -287,6 +323,11 @@ def main() -> int:
     elapsed = time.perf_counter() - t0
     session.close()
     stats = acc
+    if rec_dir is not None:
+        import shutil
+
+        rec_files = sum(len(fs) for _, _, fs in os.walk(rec_dir))
+        shutil.rmtree(rec_dir, ignore_errors=True)
 
     tot = dict(sims=stats.total_simulations, games=stats.total_games, nn=stats.total_nn_evals,
                desc=stats.total_nn_evals + stats.total_terminals, positions=stats.total_positions,
@@ -345,7 +386,10 @@ def main() -> int:
         "config": {"workload": "7x7 open PyRat, 10 cheese, 50 turns, " + workload,
                    "step": f"{args.batch_steps} passes of gather -> evaluate -> backup (+ tree reuse) over all resident games "
                            "of a persistent session; finished games are replaced at once from an endless seeded supply",
-                   "resident_games_per_gpu": args.resident, "batch_steps_per_step": args.batch_steps,
+                   # what the library put on the device (it bounds the request by the memory the trees need), not the argument
+                   "resident_games_per_gpu": info["resident_games"], "resident_games_requested": args.resident,
+                   "groups": info["groups"], "gather_pass_limit": info["gather_pass_limit"],
+                   "tree_region_GB": info["tree_region_bytes"] / 2 ** 30, "batch_steps_per_step": args.batch_steps,
                    "parallelism": f"games sharded over {world} GPU(s), no collective"},
         # the three rates side by side: `value` counts root visits per finished move, which includes the visits
         # a reused subtree brings along; descents are what the search actually walks; evaluations are network calls
@@ -375,34 +419,35 @@ def main() -> int:
         },
         "timing": {"session_open_s": t_open, "timed_s": elapsed},
     }
+    if args.record:
+        out["record"] = {"what": "every finished game's record built on the host (sink callback) and written as bundles to a "
+                                 "tmpfs inside the timed region", "games_in_callback": rec_games[0], "bundle_files": rec_files}
     # Extra leg (N=1, network evaluators): the same workload with the games as ONE group, i.e. the gather kernel launched
     # over all resident games at once instead of two half-size launches pipelined against the evaluator. It is the
     # kernel's best per-launch figure; the timed configuration above trades it for throughput.
     if has_net and world == 1 and not args.no_full_launch and "AR_GROUPS" not in os.environ and \
             (time.perf_counter() - T_START) < args.deadline - 120.0:
-        # In a child process: the leg is an extra, and nothing that goes wrong in it -- not even a crash of the runtime --
-        # may cost the line above. (The session of the timed region is closed: its device memory is free.)
-        import subprocess
+        prof = under_profiler()
+        if prof:
+            out["roofline"]["full_launch"] = {"skipped": "profiler", "seen": prof}
+        else:
+            try:
+                from alpharat_amd.sampling import release_device_memory
 
-        try:
-            from alpharat_amd.sampling import release_device_memory
-
-            release_device_memory(local_rank)  # (the arena block this process keeps cached between sessions)
-            left = max(args.deadline - (time.perf_counter() - T_START), 60.0)
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--full-launch-child", "--evaluator", args.evaluator,
-                                "--resident", str(args.resident), "--batch-steps", str(args.batch_steps)],
-                               env=dict(os.environ, AR_GROUPS="1"), capture_output=True, text=True, timeout=left)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode == 0 and lines:
-                out["roofline"]["full_launch"] = json.loads(lines[-1])
-            else:
-                out["roofline"]["full_launch"] = {"error": f"child exited with {r.returncode}: {r.stderr.strip()[-300:]}"}
-        except Exception as e:  # noqa: BLE001 -- the extra leg never costs the headline line
-            out["roofline"]["full_launch"] = {"error": str(e)}
+                release_device_memory(local_rank)  # (the arena block this process keeps cached between sessions)
+                out["roofline"]["full_launch"] = full_launch_leg(args.evaluator, args.resident, args.batch_steps, local_rank)
+            except Exception as e:  # noqa: BLE001 -- the extra leg never costs the headline line
+                out["roofline"]["full_launch"] = {"error": str(e)}
     if not args.no_cpu_baseline and args.cpu_secs > 0 and world == 1:  # a reported baseline, timed on rank 0 at N=1 only
         left = args.deadline + 60.0 - (time.perf_counter() - T_START)
         if left > args.cpu_secs + 15.0:
             out["cpu_baseline"] = cpu_baseline(weights, args.evaluator, args.cpu_secs)
+            if args.cpu_sweep:  # SURVEY 8d / bench_selfplay.rs:213-224: 1, 8, 32, 64, all threads (bounded samples)
+                cores = os.cpu_count() or 1
+                out["cpu_baseline"]["sweep"] = [
+                    {k: v for k, v in cpu_baseline(weights, args.evaluator, min(args.cpu_secs, 8.0), threads=t).items()
+                     if k in ("value", "wall_rate", "cores", "games_per_sec")}
+                    for t in sorted({1, 8, 32, 64, cores}) if t <= cores]
         else:
             out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)

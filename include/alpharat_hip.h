@@ -237,6 +237,19 @@ int ar_selfplay_open(const ArSelfPlayParams* params, ArProgress* progress, ArGam
 int ar_selfplay_step(ArSelfPlaySession* session, uint32_t batch_steps, ArSelfPlayStats* window, int* finished);
 int ar_selfplay_close(ArSelfPlaySession* session, ArSelfPlayStats* total);
 
+/* What the library chose for a session (the resident count may be smaller than `concurrent_games`: it is bounded by the
+ * device memory the trees need). gather_kind: 0 one lane per game (k_gather), 1 eight lanes per game (k_gather8), 2 the
+ * work queue over tree levels (k_gatherw), 3 fused SmartUniform step (k_step_uniform). */
+typedef struct ArSessionInfo {
+    uint32_t resident_games, groups, gather_kind;
+    uint32_t gather_pass_limit; /* k_gatherw: passes per launch (UINT32_MAX: no limit) */
+    uint64_t tree_region_bytes; /* device memory set aside for the trees */
+    uint64_t host_grown_arenas; /* trees that outgrew a run of pages and were moved to an arena of their own */
+    uint32_t idle_slots;        /* slots waiting for room in their zone of the tree region (resident games = resident_games - idle_slots) */
+    float tree_pages_per_game;  /* what the resident set is sized by: pages a game of this run holds after a few moves */
+} ArSessionInfo;
+int ar_selfplay_info(const ArSelfPlaySession* session, ArSessionInfo* out);
+
 /* Bundle writer on its own (recording.rs:23-162 write_bundle): used by the known-answer test. */
 int ar_write_bundle(const ArGameRecordView* games, uint32_t n, const char* path);
 
