@@ -49,10 +49,6 @@ struct NetDev {
     int n_head, Kh;
     const float* cmaze;      // [n_mazes][H] first-layer maze contribution incl. bias
     int n_mazes;
-    // PyRatMLP on split-bf16 matrix products (k_mlp_bf16): three bf16 planes (hi, mid, lo) of the two hidden layers'
-    // weights in MFMA operand order, [k16][column tile][lane][8]; null when the network does not qualify
-    const void *w1p[3], *w2p[3];
-    int nk1, nk2;            // 16-deep k-steps of layer 1 (non-maze inputs, zero-padded) and layer 2
 };
 
 struct Blob {
@@ -653,208 +649,6 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
             for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = hh[k];
     }
 }
-// ---- PyRatMLP with the two hidden layers on the bf16 matrix pipe at fp32 accuracy ---------------------------------
-// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA. A float is the exact sum of three bf16 values
-// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 8 + 8 + 8 mantissa bits), so a product a*b is the sum
-// of nine bf16 x bf16 products, each exact in the fp32 accumulator; the six of them above 2^-24 of a*b --
-// hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi -- reproduce the fp32 product to ~2^-23, i.e. six MFMAs of 32 cycles
-// for 16 k-steps instead of eight fp32 MFMAs of 64 cycles: 2.7x fewer matrix-pipe cycles. Measured against the fp32
-// reference on the golden network: max |logit error| 6e-8 (three terms: 1.2e-5, which would not meet the 1e-5 bar).
-// The weights are split on the host (net_build); activations are split in registers after the LDS read. The first
-// layer's operand is one-hot except six scalars: its hi plane is exact and mid / lo are zero for the first nine
-// k16-steps, which therefore need three MFMAs. Heads stay on the fp32 16x16x4 tiles (12 rows: negligible).
-// Accumulation order differs from the scalar loops, so outputs differ from k_mlp_mfma's in the last bits (not from
-// each other between launches or tile positions: a leaf's evaluation is a function of the leaf alone).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ inline void split8(const float* x, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)x[j];
-        const float r1 = x[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[j] = h;
-        mid[j] = m;
-        lo[j] = (__bf16)r2;
-    }
-}
-template <int NW>
-__global__ void __launch_bounds__(NTHREADS) k_mlp_bf16(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
-                                                       uint32_t n_fixed, const char* boards, size_t board_stride,
-                                                       ar::EvalOut* out, float* logits) {
-    constexpr int MT = 2, L = 32 * MT;
-    extern __shared__ float smem[];
-    const int H = net.H, hw = net.hw, ld = H + 4, n_ct = H >> 5;
-    float* act = smem;  // [L][ld], both hidden layers in turn
-    __shared__ LeafFeat feat[L];
-    __shared__ unsigned long long cheese[L][4];
-    __shared__ float hl[L * 12];
-    const uint32_t n = qcount ? *qcount : n_fixed;
-    const uint32_t base = blockIdx.x * L;
-    if (base >= n) return;
-    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
-    const int tid = threadIdx.x;
-    if (tid < L) {
-        const int l = tid < cnt ? tid : 0;
-        const ar::LeafReq<NW>& r = q[base + l];
-        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
-        leaf_features<NW>(r.st, b, hw, feat[tid]);
-        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int ct0 = 2 * wave;  // this wavefront's two column tiles: columns 64 wave .. 64 wave + 63
-    const bool has = ct0 < n_ct, two = ct0 + 1 < n_ct;
-    f32x16 c[MT][2];
-    const bf16x8* w1[3] = {(const bf16x8*)net.w1p[0], (const bf16x8*)net.w1p[1], (const bf16x8*)net.w1p[2]};
-    const bf16x8* w2[3] = {(const bf16x8*)net.w2p[0], (const bf16x8*)net.w2p[1], (const bf16x8*)net.w2p[2]};
-    // B fragments of one k16-step: [plane][column tile]
-    auto load_b = [&](const bf16x8* const* w, int k16, bf16x8 (&b)[3][2]) {
-        const size_t at = ((size_t)k16 * n_ct + ct0) * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            b[p][0] = w[p][at];
-            b[p][1] = w[p][at + (two ? 64 : 0)];
-        }
-    };
-    auto mma6 = [&](const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8 (&b)[3][2], int t) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[0][j], c[t][j], 0, 0, 0);  // smallest terms first
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[1][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b[0][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0][j], c[t][j], 0, 0, 0);
-        }
-    };
-    auto mma3 = [&](const bf16x8& ah, const bf16x8 (&b)[3][2], int t) {  // an operand that IS bf16 (one-hot inputs)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[2][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[1][j], c[t][j], 0, 0, 0);
-            c[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b[0][j], c[t][j], 0, 0, 0);
-        }
-    };
-    auto store_relu = [&]() {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-                act[(size_t)i * ld + 32 * ct0 + r] = fmaxf(c[t][0][v], 0.0f);
-                if (two) act[(size_t)i * ld + 32 * ct0 + 32 + r] = fmaxf(c[t][1][v], 0.0f);
-            }
-    };
-    if (has) {
-        // ---- first layer: x = [p1 one-hot | p2 one-hot | cheese mask | six scalars], accumulator = per-maze constant
-        int p1[MT], p2[MT];
-        unsigned long long ch[MT][NW];
-        float sc[MT][6];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const LeafFeat& f = feat[32 * t + r];
-            p1[t] = f.p1;
-            p2[t] = f.p2;
-            for (int s6 = 0; s6 < 6; ++s6) sc[t][s6] = f.sc[s6];
-            for (int w = 0; w < NW; ++w) ch[t][w] = cheese[32 * t + r][w];
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
-                const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + 32 * ct0 + r;
-                c[t][0][v] = cm[0];
-                c[t][1][v] = cm[two ? 32 : 0];
-            }
-        auto x_of = [&](int kk, int t) -> float {
-            if (kk < hw) return kk == p1[t] ? 1.0f : 0.0f;
-            if (kk < 2 * hw) return kk - hw == p2[t] ? 1.0f : 0.0f;
-            if (kk < 3 * hw) {
-                const int bit = kk - 2 * hw;
-                unsigned long long word = ch[t][0];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) word = (bit >> 6) == w ? ch[t][w] : word;
-                return (word >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
-            }
-            const int s6 = kk - 3 * hw;
-            float v = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
-            return v;
-        };
-        bf16x8 bw[3][2], bn[3][2];
-        load_b(w1, 0, bw);
-        for (int k16 = 0; k16 < net.nk1; ++k16) {
-            if (k16 + 1 < net.nk1) load_b(w1, k16 + 1, bn);
-            const bool exact = 16 * k16 + 16 <= 3 * hw;  // block-uniform: no scalar input in this step
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = x_of(16 * k16 + 8 * h + j, t);
-                bf16x8 ah, am, al;
-                split8(x, ah, am, al);
-                if (exact) mma3(ah, bw, t);
-                else mma6(ah, am, al, bw, t);
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                bw[p][0] = bn[p][0];
-                bw[p][1] = bn[p][1];
-            }
-        }
-        store_relu();
-    }
-    __syncthreads();
-    if (has) {
-        // ---- second layer: result held in the accumulators until every wavefront is done reading `act`
-        const float b0 = net.b2[32 * ct0 + r], b1 = net.b2[32 * ct0 + (two ? 32 : 0) + r];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                c[t][0][v] = b0;
-                c[t][1][v] = b1;
-            }
-        bf16x8 bw[3][2], bn[3][2];
-        load_b(w2, 0, bw);
-        for (int k16 = 0; k16 < net.nk2; ++k16) {
-            if (k16 + 1 < net.nk2) load_b(w2, k16 + 1, bn);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const float4* ap = (const float4*)(act + (size_t)(32 * t + r) * ld + 16 * k16 + 8 * h);
-                const float4 a0 = ap[0], a1 = ap[1];
-                const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                bf16x8 ah, am, al;
-                split8(x, ah, am, al);
-                mma6(ah, am, al, bw, t);
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                bw[p][0] = bn[p][0];
-                bw[p][1] = bn[p][1];
-            }
-        }
-    }
-    __syncthreads();
-    if (has) store_relu();
-    __syncthreads();
-    heads_mfma16(net.wh, net.bh, 12, H, act, ld, hl, tid, 2 * MT);
-    __syncthreads();
-    if (tid < cnt) {
-        const float* hh = hl + tid * 12;
-        ar::EvalOut o;
-        softmax5(hh, o.p1);
-        softmax5(hh + 5, o.p2);
-        o.v1 = softplusf(hh[10]);
-        o.v2 = softplusf(hh[11]);
-        out[base + tid] = o;
-        if (logits)
-            for (int k = 0; k < 10; ++k) logits[(size_t)(base + tid) * 10 + k] = hh[k];
-    }
-}
 
 __host__ __device__ inline bool mlp_all_mfma(int H) { return (H & 31) == 0 && H <= 64 * (NTHREADS / 64); }
 static const int MLP_MFMA_MT = 2;  // 64 leaves per block
@@ -971,174 +765,6 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric(NetDev net, const ar::Le
     }
 }
 
-// ---- SymmetricMLP on the matrix cores (hidden width a multiple of 32, at most 256) ----------------------
-// One block = 32 leaves, four wavefronts; wavefront w owns output columns 64 w .. 64 w + 63 of every layer
-// (two 32x32 accumulator tiles). Every layer is the k-ordered chain k_symmetric's loops compute -- products
-// with a 0 input add nothing, a one-hot input adds the weight row itself -- so the two kernels give the same
-// bits; here the weights stream through once per block and the multiply-adds run on v_mfma_f32_32x32x2_f32:
-//   shared encoder   acc = maze constant;  k over [cheese mask hw | progress]            (operand from registers)
-//   player encoder   acc = bias;           k over [position one-hot hw | mud | score]    (operand from registers)
-//   trunk 1          acc = bias;           k over the shared encoding, then the player's (LDS A, LDS B)
-//   trunk 2          acc = bias;           k over trunk 1                                (LDS B)
-//   heads            on v_mfma_f32_16x16x4_f32: k over h_p, then over h_1 + h_2          (LDS A, LDS B)
-// Two LDS activation buffers are enough: a layer's output waits in the accumulators until every wavefront has
-// read the buffer it will overwrite, and player 1's trunk output h_1 stays in registers while player 2 is
-// computed (it only has to be in LDS for the heads).
-template <int NW>
-__global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
-                                                             uint32_t n_fixed, const char* boards, size_t board_stride,
-                                                             ar::EvalOut* out, float* logits) {
-    constexpr int L = 32;
-    extern __shared__ float smem[];
-    const int H = net.H, hw = net.hw, ld = H + 4;
-    float* bufA = smem;                    // shared encoding, later h_1          [L][ld]
-    float* bufB = smem + (size_t)L * ld;   // player encoding / trunk 1, later h_2 [L][ld]
-    __shared__ LeafFeat feat[L];
-    __shared__ unsigned long long cheese[L][4];
-    __shared__ float hl[L * 12];
-    const uint32_t n = qcount ? *qcount : n_fixed;
-    const uint32_t base = blockIdx.x * L;
-    if (base >= n) return;
-    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
-    const int tid = threadIdx.x;
-    if (tid < L) {
-        const int l = tid < cnt ? tid : 0;
-        const ar::LeafReq<NW>& r = q[base + l];
-        const ar::Board& b = *(const ar::Board*)(boards + (size_t)r.slot * board_stride);
-        leaf_features<NW>(r.st, b, hw, feat[tid]);
-        for (int k = 0; k < 4; ++k) cheese[tid][k] = k < NW ? r.st.cheese[k] : 0ULL;
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int n0 = wave * 64;
-    const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
-    const int c1 = two ? 32 : 0;
-    // this lane's leaf (row r of the tile) as first-layer operands
-    const LeafFeat f = feat[r];
-    unsigned long long ch[NW];
-    for (int w = 0; w < NW; ++w) ch[w] = cheese[r][w];
-    f32x16 c[1][2], h1[2];
-    auto store_relu = [&](float* buf) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-            buf[(size_t)i * ld + n0 + r] = fmaxf(c[0][0][v], 0.0f);
-            if (two) buf[(size_t)i * ld + n0 + 32 + r] = fmaxf(c[0][1][v], 0.0f);
-        }
-    };
-    auto init_bias = [&](const float* bias) {
-        const float b0 = bias[n0 + r], b1 = bias[n0 + c1 + r];
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            c[0][0][v] = b0;
-            c[0][1][v] = b1;
-        }
-    };
-    // ---- shared encoder -> A
-    if (has) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-            const float* cm = net.cmaze + (size_t)feat[i].maze_id * H + n0 + r;
-            c[0][0][v] = cm[0];
-            c[0][1][v] = cm[c1];
-        }
-        auto x_sh = [&](int k, int) -> float {
-            const int kk = k + h;
-            if (kk < hw) {
-                unsigned long long word = ch[0];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) word = (kk >> 6) == w ? ch[w] : word;
-                return (word >> (kk & 63)) & 1ULL ? 1.0f : 0.0f;
-            }
-            return kk == hw ? f.sc[1] : 0.0f;
-        };
-        mfma_pass<1, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, hw + 1, H, h, x_sh, c);
-        store_relu(bufA);
-    }
-    for (int p = 0; p < 2; ++p) {
-        // ---- player encoder -> B (everybody is done reading B: see the barriers below)
-        if (has) {
-            init_bias(net.bp);
-            const int pos = p == 0 ? f.p1 : f.p2;
-            const float mud = f.sc[2 + p], score = f.sc[4 + p];
-            auto x_pe = [&](int k, int) -> float {
-                const int kk = k + h;
-                if (kk < hw) return kk == pos ? 1.0f : 0.0f;
-                return kk == hw ? mud : kk == hw + 1 ? score : 0.0f;
-            };
-            mfma_pass<1, 8>(net.wpt + (size_t)h * H + n0 + r, two, hw + 2, H, h, x_pe, c);
-            store_relu(bufB);
-        }
-        __syncthreads();
-        // ---- trunk 1: k over A (shared), then over B (player); result waits in the accumulators
-        if (has) {
-            init_bias(net.b2);
-            const float* ap = bufA + (size_t)r * ld + h;
-            auto a_sh = [&](int k, int) -> float { return ap[k]; };
-            mfma_pass<1, 8>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_sh, c);
-            const float* bp = bufB + (size_t)r * ld + h;
-            auto a_pe = [&](int k, int) -> float { return bp[k]; };
-            mfma_pass<1, 8>(net.w2t + (size_t)(H + h) * H + n0 + r, two, H, H, h, a_pe, c);
-        }
-        __syncthreads();
-        if (has) store_relu(bufB);
-        __syncthreads();
-        // ---- trunk 2: k over B
-        if (has) {
-            init_bias(net.b3);
-            const float* bp = bufB + (size_t)r * ld + h;
-            auto a_t1 = [&](int k, int) -> float { return bp[k]; };
-            mfma_pass<1, 8>(net.w3t + (size_t)h * H + n0 + r, two, H, H, h, a_t1, c);
-            if (p == 0) {
-                h1[0] = c[0][0];
-                h1[1] = c[0][1];
-            }
-        }
-        __syncthreads();  // B may be overwritten (next player's encoding, or h_2)
-    }
-    if (has) {
-        store_relu(bufB);  // h_2
-        c[0][0] = h1[0];
-        c[0][1] = h1[1];
-        store_relu(bufA);  // h_1 (the shared encoding is no longer needed)
-    }
-    __syncthreads();
-    // ---- heads on cat(h_p, h_1 + h_2): wavefront = (player, 16-leaf half); rows: policy 5, value 1
-    {
-        const int pl = wave >> 1, half = wave & 1, rr = lane & 15, qq = lane >> 4;
-        const bool col = rr < 6;
-        const float* hp = (pl == 0 ? bufA : bufB) + (size_t)(half * 16 + rr) * ld + qq;
-        const float* ha = bufA + (size_t)(half * 16 + rr) * ld + qq;
-        const float* hb = bufB + (size_t)(half * 16 + rr) * ld + qq;
-        const float* wp = net.wh + (size_t)(col ? rr : 0) * (2 * H) + qq;
-        const float b = col ? net.bh[rr] : 0.0f;
-        f32x4 acc = {b, b, b, b};
-#pragma unroll 8
-        for (int k = 0; k < H; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hp[k], col ? wp[k] : 0.0f, acc, 0, 0, 0);
-#pragma unroll 8
-        for (int k = 0; k < H; k += 4)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[k] + hb[k], col ? wp[H + k] : 0.0f, acc, 0, 0, 0);
-        if (col)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) hl[(half * 16 + 4 * qq + v) * 12 + pl * 6 + rr] = acc[v];
-    }
-    __syncthreads();
-    if (tid < cnt) {
-        const float* hh = hl + tid * 12;
-        ar::EvalOut o;
-        softmax5(hh, o.p1);
-        softmax5(hh + 6, o.p2);
-        o.v1 = softplusf(hh[5]);
-        o.v2 = softplusf(hh[11]);
-        out[base + tid] = o;
-        if (logits)
-            for (int k = 0; k < 5; ++k) {
-                logits[(size_t)(base + tid) * 10 + k] = hh[k];
-                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
-            }
-    }
-}
 // ---- the same with BOTH players of a leaf in one pass ------------------------------------------------------------
 // k_symmetric_mfma streams the trunk's weights (the bulk: (2H + H) x H) through once per player per 32-leaf block,
 // ~49 KB of L2 reads per leaf. Here a block's rows are (player, leaf) pairs -- 64 rows for 32 leaves -- so the player
@@ -1376,43 +1002,6 @@ struct ArNet {
     }
 };
 
-// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does)
-static inline uint16_t ar_f2bf(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-static inline float ar_bf2f(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// rows [row0, row0 + K) of a transposed weight matrix wt[in][H] as three bf16 planes in the B-operand order of
-// v_mfma_f32_32x32x16_bf16: [k16][column tile][lane][8], lane l holds column 32 ct + (l & 31), k = 16 k16 + 8 (l >> 5) + j
-static void ar_split_planes(const std::vector<float>& wt, int row0, int K, int H, std::vector<uint16_t> (&planes)[3], int& nk) {
-    nk = (K + 15) / 16;
-    const int n_ct = H / 32;
-    for (auto& pl : planes) pl.assign((size_t)nk * n_ct * 64 * 8, 0);
-    for (int k16 = 0; k16 < nk; ++k16)
-        for (int ct = 0; ct < n_ct; ++ct)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 16 * k16 + 8 * (lane >> 5) + j, col = 32 * ct + (lane & 31);
-                    if (k >= K) continue;
-                    const float x = wt[(size_t)(row0 + k) * H + col];
-                    const uint16_t hi = ar_f2bf(x);
-                    const float r1 = x - ar_bf2f(hi);
-                    const uint16_t mid = ar_f2bf(r1);
-                    const float r2 = r1 - ar_bf2f(mid);
-                    const size_t at = (((size_t)k16 * n_ct + ct) * 64 + lane) * 8 + j;
-                    planes[0][at] = hi;
-                    planes[1][at] = mid;
-                    planes[2][at] = ar_f2bf(r2);
-                }
-}
-
 static int net_build(const arnet::Blob& b, ArNet* net) {
     using namespace arnet;
     std::string err;
@@ -1431,19 +1020,9 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         d.H = (int)out;
         d.w1t = net->upload(wt, ok);
         d.b1 = net->upload(bias, ok);
-        const bool split = mlp_all_mfma(d.H);
-        std::vector<uint16_t> planes[3];
-        if (split) {  // the non-maze rows of layer 1 (the maze rows are the per-maze constant)
-            ar_split_planes(wt, 4 * d.hw, 3 * d.hw + 6, d.H, planes, d.nk1);
-            for (int p3 = 0; p3 < 3; ++p3) d.w1p[p3] = net->upload_raw(planes[p3].data(), planes[p3].size() * 2, ok);
-        }
         if (!fold_linear(b, "trunk.4", "trunk.5", wt, bias, in, out, err)) return nets_fail(AR_E_BACKEND, err);
         d.w2t = net->upload(wt, ok);
         d.b2 = net->upload(bias, ok);
-        if (split) {
-            ar_split_planes(wt, 0, d.H, d.H, planes, d.nk2);
-            for (int p3 = 0; p3 < 3; ++p3) d.w2p[p3] = net->upload_raw(planes[p3].data(), planes[p3].size() * 2, ok);
-        }
         std::vector<float> wh((size_t)12 * d.H), bh(12);
         const char* heads[3] = {"policy_p1_head", "policy_p2_head", "value_head"};
         const int rows[3] = {5, 5, 2};
@@ -1614,12 +1193,8 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     if (n_max == 0) return AR_OK;
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
     static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
-    // the split-bf16 kernel is opt-in: measured no faster than the fp32-MFMA kernel on the bench workload (DESIGN.md
-    // section 7: the activation splits cost the VALU what the matrix pipe saves), and the fp32 kernel is bit-identical
-    // to the scalar loops
-    const bool mlp_bf16 = mlp_mfma && net->dev.w1p[0] != nullptr && getenv("AR_MLP_BF16") != nullptr;
     const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA");
-    const int tile = mlp_bf16 ? 64 : mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
+    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
                                                                         : sym_mfma ? 32 : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
     if (net->dev.arch == ARCH_CNN) {
@@ -1628,13 +1203,6 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
         hipLaunchKernelGGL(k_cnn<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max, boards,
                            board_stride, net->bound_pool, out, logits);
-    } else if (mlp_bf16) {
-        const size_t smem = (size_t)64 * (net->dev.H + 4) * 4;
-        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_mlp_bf16<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)smem) != hipSuccess)
-            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
-        hipLaunchKernelGGL(k_mlp_bf16<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
-                           board_stride, out, logits);
     } else if (mlp_mfma) {
         const size_t smem = (size_t)32 * mlp_mt * (net->dev.H + 4) * 4;
         const void* fn = mlp_mt == 1 ? (const void*)k_mlp_mfma<NW, 1> : (const void*)k_mlp_mfma<NW, 2>;
@@ -1653,19 +1221,12 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
         hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
-    } else if (sym_mfma && getenv("AR_SYM_PER_PLAYER") == nullptr) {
+    } else if (sym_mfma) {
         const size_t smem = (size_t)3 * 32 * (net->dev.H + 4) * 4;
         if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric_mfma2<NW>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
         hipLaunchKernelGGL(k_symmetric_mfma2<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
-                           board_stride, out, logits);
-    } else if (sym_mfma) {
-        const size_t smem = (size_t)2 * 32 * (net->dev.H + 4) * 4;
-        if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric_mfma<NW>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
-        hipLaunchKernelGGL(k_symmetric_mfma<NW>, dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
     } else {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric<NW>,
