@@ -167,10 +167,12 @@ def load() -> C.CDLL:
 
     torch = sys.modules.get("torch")
     runtime_up = bool(torch is not None and getattr(torch, "cuda", None) is not None and torch.cuda.is_initialized())
-    if runtime_up:
-        os.environ.setdefault("AR_HW_QUEUES_UNKNOWN", "1")  # the library then keeps one group of games (no extra streams)
-    else:
+    if not runtime_up:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    elif "GPU_MAX_HW_QUEUES" not in os.environ:
+        # nobody asked for more queues before the runtime came up: it has its default four, and setting the variable now
+        # would only make the library believe otherwise -- it then keeps one group of games (no extra streams)
+        os.environ.setdefault("AR_HW_QUEUES_UNKNOWN", "1")
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -222,11 +222,14 @@ def main() -> int:
                          "(device memory), the line reports what it used")
     ap.add_argument("--evaluator", choices=sorted(WORKLOADS), default="mlp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-secs", type=float, default=15.0, help="bound of the CPU baseline sample")
+    ap.add_argument("--cpu-secs", type=float, default=8.0, help="bound of the CPU baseline sample")
     ap.add_argument("--no-full-launch", action="store_true",
                     help="skip the extra leg that times the gather kernel launched over all resident games at once")
     ap.add_argument("--deadline", type=float, default=480.0,
                     help="seconds after process start at which the timed loop stops early and reports the steps done")
+    ap.add_argument("--warmup-batch-steps", type=int, default=0,
+                    help="warm up for this many batch steps instead of --warmup steps (the extra evaluators' lines: a game of "
+                         "config 4 lasts about 2900 batch steps, of config 5 about 4400; a steady-state window starts after that)")
     ap.add_argument("--record", action="store_true",
                     help="also build every finished game's record on the host and write the bundles (the reference's "
                          "recording path) inside the timed region: a sink callback + output_dir on a tmpfs")
@@ -301,8 +304,16 @@ def main() -> int:
                               device_index=local_rank, **{"output_dir": None, **extra}, **search)
     info = session.info()
     t_open = time.perf_counter() - T_START
-    for _ in range(args.warmup):
-        session.step(args.batch_steps)
+    warm_done = 0
+    if args.warmup_batch_steps > 0:
+        while warm_done < args.warmup_batch_steps:
+            n = min(1024, args.warmup_batch_steps - warm_done)
+            session.step(n)
+            warm_done += n
+    else:
+        for _ in range(args.warmup):
+            session.step(args.batch_steps)
+        warm_done = args.warmup * args.batch_steps
 
     sync()
     t0 = time.perf_counter()
@@ -417,6 +428,9 @@ def main() -> int:
                      "avg_step_ms": stats.device_secs / max(stats.steps, 1) * 1e3, "algorithmic_bytes": step_bytes,
                      "achieved_GBps": step_bytes / max(stats.device_secs, 1e-9) / 1e9},
         },
+        # how much of a game's life the window covers (steady state needs the warm-up to be longer than a game)
+        "window": {"warmup_batch_steps": warm_done, "timed_batch_steps": int(tot["done"]) * args.batch_steps,
+                   "games_finished": int(tot["games"]), "positions_finished": int(tot["positions"])},
         "timing": {"session_open_s": t_open, "timed_s": elapsed},
     }
     if args.record:
