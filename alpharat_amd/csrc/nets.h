@@ -1132,15 +1132,29 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         c.cb_b = net->upload(bias, ok);
         const std::vector<float>*pw = b.get("policy_head.linear.weight"), *pb = b.get("policy_head.linear.bias"),
                           *vw = b.get("value_head.linear.weight"), *vb = b.get("value_head.linear.bias");
-        if (!pw || !pb || !vw || !vb) return nets_fail(AR_E_BACKEND, "only the mlp policy head and the point value head are built");
-        std::vector<float> wh((size_t)6 * 2 * c.HD), bh(6);
+        const bool pooled = b.get("value_head.mlp.0.weight") != nullptr;  // PooledValueHead (value_head.type "pooled")
+        if (!pw || !pb || (!pooled && (!vw || !vb))) return nets_fail(AR_E_BACKEND, "unknown policy / value head in the weight blob");
+        std::vector<float> wh((size_t)6 * 2 * c.HD, 0.0f), bh(6, 0.0f);
         memcpy(wh.data(), pw->data(), pw->size() * 4);
-        memcpy(&wh[(size_t)5 * 2 * c.HD], vw->data(), vw->size() * 4);
         memcpy(bh.data(), pb->data(), 20);
-        bh[5] = (*vb)[0];
+        c.VH = 0;
+        if (pooled) {
+            if (!fold_linear(b, "value_head.mlp.0", "", wt, bias, in, out, err) || (int)in != 2 * c.C + 2 * c.HD)
+                return nets_fail(AR_E_BACKEND, "bad pooled value head");
+            c.VH = (int)out;
+            c.pv_w0 = net->upload(wt, ok);
+            c.pv_b0 = net->upload(bias, ok);
+            const std::vector<float>*w2 = b.get("value_head.mlp.2.weight"), *b2 = b.get("value_head.mlp.2.bias");
+            if (!w2 || !b2 || (int)w2->size() != c.VH) return nets_fail(AR_E_BACKEND, "bad pooled value head");
+            c.pv_w2 = net->upload(*w2, ok);
+            c.pv_b2 = net->upload(*b2, ok);
+        } else {
+            memcpy(&wh[(size_t)5 * 2 * c.HD], vw->data(), vw->size() * 4);
+            bh[5] = (*vb)[0];
+        }
         c.hd_w = net->upload(wh, ok);
         c.hd_b = net->upload(bh, ok);
-        const size_t head_floats = (size_t)CNN_TILE * (2 * (c.C + c.PD) + 2 * c.HD + 12);
+        const size_t head_floats = (size_t)CNN_TILE * (2 * (c.C + c.PD) + 2 * c.HD + 12 + 2 * c.C + 2 * c.VH);
         if (head_floats > small_floats) small_floats = head_floats;
         const size_t chs = (size_t)(c.height + 2) * (c.width + 2);
         net->smem = ((size_t)CNN_TILE * c.C * c.hw + 2 * (size_t)CNN_TILE * c.C * chs + small_floats + 64) * 4;

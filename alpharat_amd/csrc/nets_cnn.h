@@ -38,6 +38,11 @@ struct CnnDev {
     const float *pe_w, *pe_b;          // player_encoder [3][PD], [PD]
     const float *cb_w, *cb_b;          // combiner [(C+PD)][HD], [HD]
     const float *hd_w, *hd_b;          // heads rows: policy 5, value 1 over 2*HD, row-major [6][2HD]
+    // PooledValueHead (cnn/heads.py:40-68) instead of the point head's row 5: cat([mean, max of the trunk's output over
+    // the board, h_i, agg]) -> Linear(2C + 2HD -> VH) -> ReLU -> Linear(VH -> 1); VH = 0: point head
+    int VH;
+    const float *pv_w0, *pv_b0;        // [2C + 2HD][VH] (transposed), [VH]
+    const float *pv_w2, *pv_b2;        // [VH], [1]
     const uint8_t* maze;               // unused here (maze comes through the boards' maze_off)
 };
 
@@ -370,6 +375,43 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         hl[i] = acc;
     }
     __syncthreads();
+    if (net.VH > 0) {
+        const int VH = net.VH;
+        float* pool = hl + L * 12;        // [L][2C]: mean, max of the trunk's output over the board
+        float* vh = pool + L * 2 * C;     // [L][2][VH]
+        for (int i = tid; i < L * C; i += NTHREADS) {
+            const int l = i / C, c = i % C;
+            const float* a = &A[(size_t)l * a_leaf + (size_t)c * hw];
+            float s = 0.0f, mx = a[0];
+            for (int k = 0; k < hw; ++k) {
+                s += a[k];
+                mx = fmaxf(mx, a[k]);
+            }
+            pool[l * 2 * C + c] = s / (float)hw;
+            pool[l * 2 * C + C + c] = mx;
+        }
+        __syncthreads();
+        for (int i = tid; i < L * 2 * VH; i += NTHREADS) {
+            const int l = i / (2 * VH), rem = i % (2 * VH), p = rem / VH, o = rem % VH;
+            const float* hi = hid + (size_t)(l * 2 + p) * HD;
+            const float* h0 = hid + (size_t)(l * 2) * HD;
+            const float* h1 = h0 + HD;
+            const float* pl = pool + (size_t)l * 2 * C;
+            float acc = net.pv_b0[o];
+            for (int k = 0; k < 2 * C; ++k) acc = fmaf(net.pv_w0[(size_t)k * VH + o], pl[k], acc);
+            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + k) * VH + o], hi[k], acc);
+            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + HD + k) * VH + o], h0[k] + h1[k], acc);
+            vh[i] = fmaxf(acc, 0.0f);
+        }
+        __syncthreads();
+        for (int i = tid; i < L * 2; i += NTHREADS) {
+            const float* v = vh + (size_t)i * VH;
+            float acc = net.pv_b2[0];
+            for (int k = 0; k < VH; ++k) acc = fmaf(net.pv_w2[k], v[k], acc);
+            hl[(i / 2) * 12 + (i % 2) * 6 + 5] = acc;  // the value logit of leaf i / 2, player i % 2
+        }
+        __syncthreads();
+    }
     CNN_T(20);
 #if defined(AR_CNN_PROF)
     if (prof && atomicCAS(&g_cnn_prof_done, 0, 1) == 0) {

@@ -223,8 +223,9 @@ inline bool net_forward(const NetBlob& nb, const float* obs, NetOut& out, std::s
         }
     } else if (nb.arch == 2) {  // ---- PyRatCNN
         if (!need("stem.weight") || !need("combiner.0.weight") || !need("policy_head.linear.weight")) return false;
-        if (!nb.has("value_head.linear.weight")) {
-            err = "oracle: only the 'point' value head is restated";
+        const bool pooled_value = nb.has("value_head.mlp.0.weight");  // PooledValueHead (cnn/heads.py:40-68)
+        if (!pooled_value && !nb.has("value_head.linear.weight")) {
+            err = "oracle: unknown value head";
             return false;
         }
         const int H = (int)nb.height, W = (int)nb.width;
@@ -298,7 +299,27 @@ inline bool net_forward(const NetBlob& nb, const float* obs, NetOut& out, std::s
             linear(*nb.get("policy_head.linear.weight"), nb.get("policy_head.linear.bias"), cat2.data(),
                    p == 0 ? out.logits_p1 : out.logits_p2);
             float v;
-            linear(*nb.get("value_head.linear.weight"), nb.get("value_head.linear.bias"), cat2.data(), &v);
+            if (pooled_value) {
+                // cat([mean, max over the board of the trunk's output, h_i, agg]) -> Linear -> ReLU -> Linear -> softplus
+                const int HH = (int)nb.get("value_head.mlp.0.weight")->dims[0];
+                std::vector<float> vin((size_t)2 * C + 2 * HD), vh(HH);
+                for (int c = 0; c < C; ++c) {
+                    double s = 0.0;
+                    float mx = feat[(size_t)c * hw];
+                    for (int i = 0; i < hw; ++i) {
+                        s += feat[(size_t)c * hw + i];
+                        mx = feat[(size_t)c * hw + i] > mx ? feat[(size_t)c * hw + i] : mx;
+                    }
+                    vin[c] = (float)(s / hw);
+                    vin[C + c] = mx;
+                }
+                for (int i = 0; i < 2 * HD; ++i) vin[2 * C + i] = cat2[i];
+                linear(*nb.get("value_head.mlp.0.weight"), nb.get("value_head.mlp.0.bias"), vin.data(), vh.data());
+                relu(vh.data(), HH);
+                linear(*nb.get("value_head.mlp.2.weight"), nb.get("value_head.mlp.2.bias"), vh.data(), &v);
+            } else {
+                linear(*nb.get("value_head.linear.weight"), nb.get("value_head.linear.bias"), cat2.data(), &v);
+            }
             (p == 0 ? out.value_p1 : out.value_p2) = softplus(v);
         }
     } else {

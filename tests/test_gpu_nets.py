@@ -46,7 +46,8 @@ def test_device_encoder_golden(path):
 
 
 @pytest.mark.parametrize("name", ["mlp_5x5_h32", "mlp_7x7_h256", "symmetric_5x5_h32", "symmetric_7x7_h256",
-                                  "cnn_res_5x5_c16", "cnn_gpool_7x5_c16", "cnn_gpool_7x7_c64"])
+                                  "cnn_res_5x5_c16", "cnn_gpool_7x5_c16", "cnn_gpool_7x7_c64",
+                                  "cnn_pooled_7x5_c16", "cnn_pooled_7x7_c32"])  # (pooled: value_head.type "pooled")
 def test_device_net_matches_reference_outputs(name):
     from alpharat_amd.nets import Net, encode
 

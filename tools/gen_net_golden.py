@@ -148,8 +148,17 @@ def main() -> int:
             player_dim=32, hidden_dim=64, dropout=0.1)),
         ("cnn_gpool_7x5_c16", "cnn", (7, 5), dict(trunk=dict(channels=16, blocks=[
             dict(type="gpool", gpool_channels=8), dict(type="res")]), player_dim=8, hidden_dim=16)),
+        # the value head that pools the trunk's output (value_head.type "pooled", cnn/heads.py:40-68)
+        ("cnn_pooled_7x5_c16", "cnn", (7, 5), dict(trunk=dict(channels=16, blocks=[
+            dict(type="res"), dict(type="gpool", gpool_channels=8)]), value_head=dict(type="pooled"), player_dim=8,
+            hidden_dim=16)),
+        ("cnn_pooled_7x7_c32", "cnn", (7, 7), dict(trunk=dict(channels=32, blocks=[dict(type="res"), dict(type="res")]),
+                                                   value_head=dict(type="pooled"), player_dim=16, hidden_dim=32)),
     ]
+    only = set(sys.argv[1:])  # (names on the command line: regenerate just those; seeds depend on the case's index only)
     for idx, (name, arch, (w, h), kw) in enumerate(cases):
+        if only and name not in only:
+            continue
         torch.manual_seed(1000 + idx)
         gen = torch.Generator().manual_seed(2000 + idx)
         obs_dim = w * h * 7 + 6
