@@ -1851,6 +1851,8 @@ struct Engine {
         hipEvent_t gathered = nullptr;  // the group's last gather launch is complete
         uint32_t first = 0, end = 0;  // slots [first, end)
         uint64_t step = 0;
+        bool adv_pending = false;  // (late tree reuse) the last step's k_advance has not been launched yet
+        uint32_t adv_phase = 0;
     };
     // HIP events around every k_gather launch of group 0 (on the stream it runs on); read back in scan()
     std::vector<hipEvent_t> gather_ev;
@@ -1860,6 +1862,8 @@ struct Engine {
     bool overlap_advance = true;
     bool merge_per_group = false;
     bool stagger_gathers = false;
+    int cu_split = 0;  // 1: groups on the low / high half of the CU mask bits, 2: even / odd bits
+    bool adv_late = false;
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
         if (n < 1) n = 1;
@@ -1881,14 +1885,26 @@ struct Engine {
             // = 4); a fifth stream shares a queue with another and the pipeline collapses (measured: 321 M against
             // 565 M simulations/s)
             HIP_TRY(hipEventCreateWithFlags(&groups[g].gathered, hipEventDisableTiming));
-            if (g > 0) {
-                HIP_TRY(hipStreamCreateWithFlags(&groups[g].stream, hipStreamNonBlocking));
+            // (AR_CUMASK=lohi|evenodd, off by default) every group on its own half of the compute units: the streams of
+            // group g are created with a CU mask, so that kernels of different groups never share a CU
+            uint32_t mask[8];
+            const bool masked = cu_split != 0 && n == 2;
+            for (int w = 0; w < 8; ++w)
+                mask[w] = cu_split == 2 ? (g == 0 ? 0x55555555u : 0xAAAAAAAAu) : ((w < 4) == (g == 0) ? 0xFFFFFFFFu : 0u);
+            if (g > 0 || masked) {
+                if (masked)
+                    HIP_TRY(hipExtStreamCreateWithCUMask(&groups[g].stream, 8, mask));
+                else
+                    HIP_TRY(hipStreamCreateWithFlags(&groups[g].stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].done, hipEventDisableTiming));
             } else {
                 groups[g].stream = stream;
             }
             if (overlap_advance) {
-                HIP_TRY(hipStreamCreateWithFlags(&groups[g].adv_stream, hipStreamNonBlocking));
+                if (masked)
+                    HIP_TRY(hipExtStreamCreateWithCUMask(&groups[g].adv_stream, 8, mask));
+                else
+                    HIP_TRY(hipStreamCreateWithFlags(&groups[g].adv_stream, hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].backed_up, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].adv_done, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&groups[g].adv_ev[0], hipEventDisableTiming));
@@ -1947,6 +1963,8 @@ struct Engine {
             gather_ev_used += 2;
         }
         HIP_TRY(hipEventRecord(g.gathered, g.stream));
+        if (g.adv_pending)
+            if (int rc = launch_late_advance(g)) return rc;
         if (gatherw)
             hipLaunchKernelGGL(k_pack_leaves<NW>, dim3((n + 63) / 64), dim3(64), 0, g.stream, slots.p, g.end, bases(), g.first, q, qc);
         const uint32_t n_max = (uint32_t)((size_t)n * cfg.batch_size);
@@ -1980,6 +1998,16 @@ struct Engine {
                                cfg, bases(), zig.p, ev, backup_lanes, g.first, phase);
         // blocks the group's trees left at the last step go back on the free stacks (nothing reads them any more, and
         // this stream is the only one that pops or returns in the group's zones)
+        if (side && adv_late) {
+            // (AR_ADV_LATE=1) The tree reuse of this step is launched behind the NEXT gather of the group (launch_late_advance),
+            // so that it runs beside the evaluator, which leaves the memory system alone, instead of beside the tree walk,
+            // which it slows down by a fifth (profiles/r03_sweeps.md: the gather launch with and without k_advance beside it)
+            HIP_TRY(hipEventRecord(g.backed_up, g.stream));
+            g.adv_pending = true;
+            g.adv_phase = phase;
+            g.step += 1;
+            return AR_OK;
+        }
         if (merge_per_group && pool.bits) {
             const uint32_t z0 = g.first / POOL_ZONE_SLOTS, z1 = (g.end + POOL_ZONE_SLOTS - 1) / POOL_ZONE_SLOTS;
             if (side) {
@@ -1999,6 +2027,23 @@ struct Engine {
                                (uint32_t)SLOT_ACTIVE);
         }
         g.step += 1;
+        return AR_OK;
+    }
+
+    // tree reuse of the group's previous step, on the side stream: after that step's backup and (when a gather has been
+    // launched since) after that gather
+    int launch_late_advance(Group& g) {
+        const uint32_t n = g.end - g.first;
+        HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.backed_up, 0));
+        HIP_TRY(hipStreamWaitEvent(g.adv_stream, g.gathered, 0));
+        if (merge_per_group && pool.bits) {
+            const uint32_t z0 = g.first / POOL_ZONE_SLOTS, z1 = (g.end + POOL_ZONE_SLOTS - 1) / POOL_ZONE_SLOTS;
+            hipLaunchKernelGGL(k_pool_merge, dim3(z1 - z0), dim3(64), 0, g.adv_stream, pool, z0, z1 - z0);
+        }
+        hipLaunchKernelGGL(k_advance<NW>, dim3(n), dim3(64), 0, g.adv_stream, slots.p, g.end, bases(), cfg, g.first, g.adv_phase,
+                           (uint32_t)SLOT_READY_A + g.adv_phase);
+        HIP_TRY(hipEventRecord(g.adv_ev[g.adv_phase], g.adv_stream));
+        g.adv_pending = false;
         return AR_OK;
     }
 
@@ -2042,6 +2087,9 @@ struct Engine {
             for (int k = 0; k < n_launch * iters; ++k)
                 for (Group& g : groups)
                     if (int rc = group_step(g)) return rc;
+            for (Group& g : groups)
+                if (g.adv_pending)
+                    if (int rc = launch_late_advance(g)) return rc;
             for (const Group& g : groups) {
                 if (g.stream != stream) {
                     HIP_TRY(hipEventRecord(g.done, g.stream));
@@ -2587,6 +2635,8 @@ struct SelfPlaySession : SessionBase {
             if (eng.cache_entries) ng = 1;  // one probe/fill pair in flight at a time: a reader never overlaps an eviction
             if (getenv("AR_NO_ADVANCE_OVERLAP")) eng.overlap_advance = false;
             if (getenv("AR_STAGGER")) eng.stagger_gathers = true;
+            if (const char* e = getenv("AR_ADV_LATE")) eng.adv_late = atoi(e) != 0;
+            if (const char* e = getenv("AR_CUMASK")) eng.cu_split = std::string(e) == "lohi" ? 1 : std::string(e) == "evenodd" ? 2 : 0;
             if (int rc = eng.make_groups(ng)) return rc;
         }
         if (const char* e = getenv("AR_LANES_PER_WAVE"))

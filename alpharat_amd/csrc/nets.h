@@ -492,9 +492,37 @@ __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h
         wb[j] = k + h < K ? bp1[(size_t)k * H] : 0.0f;
     }
     // whole chunks of R steps are straight-line code (a guard per step would start a new basic block, and
-    // with it conservative s_waitcnt's, in front of every MFMA); only the last, partial chunk is guarded
+    // with it conservative s_waitcnt's, in front of every MFMA); only the last, partial chunk is guarded.
+    // While the chunk after the current one lies wholly inside K its loads carry no guard either: a guarded
+    // load is a branch around the instruction, and the compiler then waits for every load in flight before
+    // the first MFMA of the chunk instead of counting them.
     const int K_main = K - K % (2 * R);
     int k0 = 0;
+    for (; k0 + 4 * R <= K; k0 += 2 * R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int k = k0 + 2 * R + 2 * j;
+            na[j] = bp0[(size_t)k * H];
+            nb[j] = bp1[(size_t)k * H];
+        }
+        // the loads go out before the chunk's MFMAs (left to itself the scheduler sinks them to the end of
+        // the chunk, where the next iteration waits for them at once)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float a = a_of(k0 + 2 * j, t);
+                c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wa[j], c[t][0], 0, 0, 0);
+                c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[j], c[t][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            wa[j] = na[j];
+            wb[j] = nb[j];
+        }
+    }
     for (; k0 < K_main; k0 += 2 * R) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {  // next chunk (a load past K yields 0 without touching memory)
@@ -531,7 +559,7 @@ __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h
     }
 }
 
-template <int NW, int MT>
+template <int NW, int MT, int FL>
 __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
                                                        uint32_t n_fixed, const char* boards, size_t board_stride,
                                                        ar::EvalOut* out, float* logits) {
@@ -558,20 +586,90 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int n0 = wave * 64;
     const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
-    f32x16 c[MT][2];
-    if (has) {
-        // first layer
-        int p1[MT], p2[MT];
-        unsigned long long ch[MT][NW];
-        float sc[MT][6];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const LeafFeat& f = feat[32 * t + r];
-            p1[t] = f.p1;
-            p2[t] = f.p2;
-            for (int s6 = 0; s6 < 6; ++s6) sc[t][s6] = f.sc[s6];
-            for (int w = 0; w < NW; ++w) ch[t][w] = cheese[32 * t + r][w];
+    const int K1 = 3 * hw + 6, K1e = (K1 + 1) & ~1;
+    // The first layer's operand x, one row of K1e floats per leaf, laid out in `act` (which nothing else uses
+    // until the layer's results are written there) when it fits: the k-loop then is the second layer's loop,
+    // one LDS read per MFMA pair. Forming x in registers from the leaf's cells and cheese mask (the path kept
+    // for boards whose K1 exceeds a row of `act`) costs a dozen vector instructions and several branches per
+    // k-step and held the first layer at a third of the matrix pipe's rate.
+    // FL (first layer): 0 = x staged, the product over all K1 rows; 1 = x formed in registers (boards whose K1e exceeds a
+    // row of `act`; AR_MLP_FL=1); 2 = the p1 / p2 rows summed into the start of the chain, cheese and scalars on the matrix
+    // cores (below)
+    constexpr bool staged = FL == 0;
+    if (FL == 2) {
+        // x is one-hot over the p1 cells and over the p2 cells: the first 2 hw steps of a leaf's chain add exactly one
+        // weight row each (fma(1, w, acc) = acc + w, fma(0, w, acc) = acc), so the chain can start from
+        //   (maze constant + row of the p1 cell) + row of the p2 cell
+        // -- the same bits -- and the matrix cores only take the hw + 6 cheese and scalar rows: 28 k-steps instead of 77
+        // at 7x7. The starts are summed 16 bytes at a time into `act` and picked up from there in accumulator layout.
+        const int H4 = H >> 2;
+        for (int item = tid; item < L * H4; item += NTHREADS) {
+            const int l = item / H4, c4 = item - l * H4;
+            const LeafFeat& f = feat[l];
+            const float4 a = ((const float4*)(net.cmaze + (size_t)f.maze_id * H))[c4];
+            const float4 b = ((const float4*)(net.w1t + (size_t)(4 * hw + f.p1) * H))[c4];
+            const float4 c = ((const float4*)(net.w1t + (size_t)(5 * hw + f.p2) * H))[c4];
+            float4 sum;
+            sum.x = (a.x + b.x) + c.x;
+            sum.y = (a.y + b.y) + c.y;
+            sum.z = (a.z + b.z) + c.z;
+            sum.w = (a.w + b.w) + c.w;
+            *(float4*)(act + (size_t)l * ld + 4 * c4) = sum;
         }
+        __syncthreads();
+    }
+    if (staged) {
+        constexpr int TPL = NTHREADS / L;  // threads per leaf
+        const int l = tid / TPL;
+        const LeafFeat& f = feat[l];
+        float* x = act + (size_t)l * ld;
+        for (int kk = tid % TPL; kk < K1e; kk += TPL) {
+            float v;
+            if (kk < hw) v = kk == f.p1 ? 1.0f : 0.0f;
+            else if (kk < 2 * hw) v = kk - hw == f.p2 ? 1.0f : 0.0f;
+            else if (kk < 3 * hw) {
+                const int bit = kk - 2 * hw;
+                v = (cheese[l][bit >> 6] >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
+            } else v = kk < K1 ? f.sc[kk - 3 * hw] : 0.0f;
+            x[kk] = v;
+        }
+        __syncthreads();
+    }
+    f32x16 c[MT][2];
+    if (FL == 2) {
+        if (has) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int i = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    c[t][0][v] = act[(size_t)i * ld + n0 + r];
+                    c[t][1][v] = act[(size_t)i * ld + n0 + (two ? 32 : 0) + r];
+                }
+        }
+        __syncthreads();  // the starts are in registers: `act` now takes the operand
+        {
+            // x over [cheese | six scalars], K2e floats per leaf at the head of its row of `act`
+            const int K2 = hw + 6, K2e = (K2 + 1) & ~1;
+            constexpr int TPL = NTHREADS / L;  // threads per leaf
+            const int l = tid / TPL;
+            const LeafFeat& f = feat[l];
+            float* x = act + (size_t)l * ld;
+            for (int kk = tid % TPL; kk < K2e; kk += TPL) {
+                float v;
+                if (kk < hw) v = (cheese[l][kk >> 6] >> (kk & 63)) & 1ULL ? 1.0f : 0.0f;
+                else v = kk < K2 ? f.sc[kk - hw] : 0.0f;
+                x[kk] = v;
+            }
+        }
+        __syncthreads();
+        if (has) {
+            const float* xp = act + (size_t)r * ld + h;
+            auto x_lds = [&](int k, int t) -> float { return xp[(size_t)(32 * t) * ld + k]; };
+            mfma_pass<MT, 8>(net.w1t + (size_t)(6 * hw + h) * H + n0 + r, two, hw + 6, H, h, x_lds, c);
+        }
+    } else if (has) {
+        // first layer
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -581,24 +679,45 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_mfma(NetDev net, const ar::Lea
                 c[t][0][v] = cm[0];
                 c[t][1][v] = cm[two ? 32 : 0];
             }
-        auto x_of = [&](int k, int t) -> float {
-            const int kk = k + h;
-            if (kk < hw) return kk == p1[t] ? 1.0f : 0.0f;
-            if (kk < 2 * hw) return kk - hw == p2[t] ? 1.0f : 0.0f;
-            if (kk < 3 * hw) {
-                const int bit = kk - 2 * hw;
-                unsigned long long word = ch[t][0];
+        const float* w1 = net.w1t + (size_t)(4 * hw + h) * H + n0 + r;
+        if (staged) {
+            const float* xp = act + (size_t)r * ld + h;
+            auto x_lds = [&](int k, int t) -> float { return xp[(size_t)(32 * t) * ld + k]; };
+            mfma_pass<MT, 8>(w1, two, K1, H, h, x_lds, c);
+        } else {
+            int p1[MT], p2[MT];
+            unsigned long long ch[MT][NW];
+            float sc[MT][6];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) word = (bit >> 6) == w ? ch[t][w] : word;
-                return (word >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
+            for (int t = 0; t < MT; ++t) {
+                const LeafFeat& f = feat[32 * t + r];
+                p1[t] = f.p1;
+                p2[t] = f.p2;
+                for (int s6 = 0; s6 < 6; ++s6) sc[t][s6] = f.sc[s6];
+                for (int w = 0; w < NW; ++w) ch[t][w] = cheese[32 * t + r][w];
             }
-            const int s6 = kk - 3 * hw;
-            float v = 0.0f;
+            auto x_of = [&](int k, int t) -> float {
+                const int kk = k + h;
+                if (kk < hw) return kk == p1[t] ? 1.0f : 0.0f;
+                if (kk < 2 * hw) return kk - hw == p2[t] ? 1.0f : 0.0f;
+                if (kk < 3 * hw) {
+                    const int bit = kk - 2 * hw;
+                    unsigned long long word = ch[t][0];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
-            return v;
-        };
-        mfma_pass<MT, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, 3 * hw + 6, H, h, x_of, c);
+                    for (int w = 1; w < NW; ++w) word = (bit >> 6) == w ? ch[t][w] : word;
+                    return (word >> (bit & 63)) & 1ULL ? 1.0f : 0.0f;
+                }
+                const int s6 = kk - 3 * hw;
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v = s6 == j ? sc[t][j] : v;
+                return v;
+            };
+            mfma_pass<MT, 8>(w1, two, K1, H, h, x_of, c);
+        }
+    }
+    if (FL != 1) __syncthreads();  // every wavefront is done reading x before the results go over it
+    if (has) {
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -1073,12 +1192,26 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         c.width = d.width;
         c.height = d.height;
         c.hw = d.hw;
-        if (d.width > 8 || d.height > 8) return nets_fail(AR_E_BACKEND, "the CNN kernel handles boards up to 8x8");
         const std::vector<float>* sw = b.get("stem.weight");
         if (!sw || b.dims.at("stem.weight").size() != 4) return nets_fail(AR_E_BACKEND, "weight blob lacks stem.weight");
         c.C = (int)b.dims.at("stem.weight")[0];
         if (b.dims.at("stem.weight")[1] != 5 || (c.C != 16 && c.C != 32 && c.C != 64))
             return nets_fail(AR_E_BACKEND, "CNN trunk must have 5 input planes and 16, 32 or 64 channels");
+        // C = 32 / 64: trunk state in registers (k_cnn_mfma), L leaves (L * hw <= 128 MT rows) per workgroup, chosen so
+        // that the image stays under 64 KB (several workgroups per CU) unless a single leaf needs more; C = 16: k_cnn
+        c.MT = 0;
+        c.L = CNN_TILE;
+        const size_t chs = (size_t)(c.height + 2) * (c.width + 2);
+        if (c.C % 32 == 0 && c.hw <= 256 && !getenv("AR_CNN_LDS")) {  // (AR_CNN_LDS: the three-image kernel, A/B knob; boards <= 8x8)
+            c.MT = c.hw > 128 ? 2 : 1;
+            c.L = 128 * c.MT / c.hw;
+            if (c.L > CNN_TILE_MAX) c.L = CNN_TILE_MAX;
+            while (c.L > 1 && (size_t)c.L * c.C * chs * 4 > 64 * 1024) c.L -= 1;
+        } else if (c.C % 32 == 0 && (c.width > 8 || c.height > 8)) {
+            return nets_fail(AR_E_BACKEND, "AR_CNN_LDS: the three-image CNN kernel handles 32 / 64 channels on boards up to 8x8");
+        }
+        const size_t TL = (size_t)c.L;
+        size_t g_max = 0;
         std::vector<double> sa, sb;
         if (!bn_affine(b, "stem_bn", c.C, sa, sb, err)) return nets_fail(AR_E_BACKEND, err);
         c.stem_w = net->upload(conv_t(*sw, c.C, 5, &sa), ok);
@@ -1118,7 +1251,9 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
                     for (int kk = 0; kk < 2 * G; ++kk) wlt[(size_t)kk * c.C + o] = (*lw)[(size_t)o * 2 * G + kk];
                 k.wl = net->upload(wlt, ok);
                 k.bl = net->upload(*lb, ok);
-                if ((size_t)CNN_TILE * (c.C + 2 * G) > small_floats) small_floats = (size_t)CNN_TILE * (c.C + 2 * G);
+                if (TL * (c.C + 2 * G) > small_floats) small_floats = TL * (c.C + 2 * G);
+                if ((size_t)G > g_max) g_max = (size_t)G;
+                if (c.MT && G > 64) return nets_fail(AR_E_BACKEND, "gpool_channels above 64");
             }
             c.n_blocks = bi + 1;
         }
@@ -1154,10 +1289,16 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
         }
         c.hd_w = net->upload(wh, ok);
         c.hd_b = net->upload(bh, ok);
-        const size_t head_floats = (size_t)CNN_TILE * (2 * (c.C + c.PD) + 2 * c.HD + 12 + 2 * c.C + 2 * c.VH);
+        const size_t head_floats = TL * (2 * (c.C + c.PD) + 2 * c.HD + 12 + 2 * c.C + 2 * c.VH);
         if (head_floats > small_floats) small_floats = head_floats;
-        const size_t chs = (size_t)(c.height + 2) * (c.width + 2);
-        net->smem = ((size_t)CNN_TILE * c.C * c.hw + 2 * (size_t)CNN_TILE * c.C * chs + small_floats + 64) * 4;
+        if (c.MT) {
+            size_t pf = TL * c.C * chs;  // the image; between blocks [L][C][hw] + [L][G][hw]
+            if (TL * (c.C + g_max) * c.hw > pf) pf = TL * (c.C + g_max) * c.hw;
+            c.p_floats = (int)pf;
+            net->smem = (pf + small_floats + 64) * 4;
+        } else {
+            net->smem = (TL * c.C * c.hw + 2 * TL * c.C * chs + small_floats + 64) * 4;
+        }
         d.H = 4;  // unused by the CNN path
     } else {
         return nets_fail(AR_E_BACKEND, "unknown architecture id in the weight blob");
@@ -1208,10 +1349,20 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
     static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
     const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA");
-    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? CNN_TILE
+    const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? net->cnn.L
                                                                         : sym_mfma ? 32 : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
-    if (net->dev.arch == ARCH_CNN) {
+    if (net->dev.arch == ARCH_CNN && net->cnn.MT) {
+        const void* fn = net->cnn.MT == 2 ? (const void*)k_cnn_mfma<NW, 2> : (const void*)k_cnn_mfma<NW, 1>;
+        if (net->smem > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) != hipSuccess)
+            return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
+        if (net->cnn.MT == 2)
+            hipLaunchKernelGGL((k_cnn_mfma<NW, 2>), dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max,
+                               boards, board_stride, net->bound_pool, out, logits);
+        else
+            hipLaunchKernelGGL((k_cnn_mfma<NW, 1>), dim3(blocks), dim3(NTHREADS), net->smem, stream, net->cnn, q, qcount, n_max,
+                               boards, board_stride, net->bound_pool, out, logits);
+    } else if (net->dev.arch == ARCH_CNN) {
         if (net->smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_cnn<NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                          (int)net->smem) != hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the CNN kernel");
@@ -1219,15 +1370,30 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
                            board_stride, net->bound_pool, out, logits);
     } else if (mlp_mfma) {
         const size_t smem = (size_t)32 * mlp_mt * (net->dev.H + 4) * 4;
-        const void* fn = mlp_mt == 1 ? (const void*)k_mlp_mfma<NW, 1> : (const void*)k_mlp_mfma<NW, 2>;
+        // first-layer variant (k_mlp_mfma's FL): 2 unless AR_MLP_FL says otherwise (read per launch: a test toggles it);
+        // 0 needs the whole observation's non-maze part in a row of `act`
+        int fl = getenv("AR_MLP_FL") ? atoi(getenv("AR_MLP_FL")) : 2;
+        const int K1e = (3 * net->dev.hw + 6 + 1) & ~1;
+        if (fl < 0 || fl > 2) fl = 2;
+        if (fl == 0 && K1e > net->dev.H + 4) fl = 1;
+        const void* fns[2][3] = {{(const void*)k_mlp_mfma<NW, 1, 0>, (const void*)k_mlp_mfma<NW, 1, 1>, (const void*)k_mlp_mfma<NW, 1, 2>},
+                                 {(const void*)k_mlp_mfma<NW, 2, 0>, (const void*)k_mlp_mfma<NW, 2, 1>, (const void*)k_mlp_mfma<NW, 2, 2>}};
+        const void* fn = fns[mlp_mt == 1 ? 0 : 1][fl];
         if (smem > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the MLP kernel");
-        if (mlp_mt == 1)
-            hipLaunchKernelGGL((k_mlp_mfma<NW, 1>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max,
-                               boards, board_stride, out, logits);
-        else
-            hipLaunchKernelGGL((k_mlp_mfma<NW, 2>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max,
-                               boards, board_stride, out, logits);
+#define AR_MLP_LAUNCH(MT_, FL_)                                                                                          \
+    hipLaunchKernelGGL((k_mlp_mfma<NW, MT_, FL_>), dim3(blocks), dim3(NTHREADS), smem, stream, net->dev, q, qcount, n_max, \
+                       boards, board_stride, out, logits)
+        if (mlp_mt == 1) {
+            if (fl == 0) AR_MLP_LAUNCH(1, 0);
+            else if (fl == 1) AR_MLP_LAUNCH(1, 1);
+            else AR_MLP_LAUNCH(1, 2);
+        } else {
+            if (fl == 0) AR_MLP_LAUNCH(2, 0);
+            else if (fl == 1) AR_MLP_LAUNCH(2, 1);
+            else AR_MLP_LAUNCH(2, 2);
+        }
+#undef AR_MLP_LAUNCH
     } else if (net->dev.arch == ARCH_MLP) {
         if (net->smem > 48 * 1024 &&
             hipFuncSetAttribute((const void*)k_mlp<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)net->smem) !=

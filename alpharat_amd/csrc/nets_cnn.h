@@ -44,6 +44,9 @@ struct CnnDev {
     const float *pv_w0, *pv_b0;        // [2C + 2HD][VH] (transposed), [VH]
     const float *pv_w2, *pv_b2;        // [VH], [1]
     const uint8_t* maze;               // unused here (maze comes through the boards' maze_off)
+    // k_cnn_mfma (trunk state in registers): MT row tiles per wavefront (0: k_cnn), L leaves per workgroup,
+    // floats of the image / scratch region P
+    int MT, L, p_floats;
 };
 
 // zero-bordered patch conv: out[l][co][y][x] = bias[co] + sum_ci sum_tap w[ci][tap][co] * in[l][ci][y+dy][x+dx]
@@ -190,12 +193,160 @@ __device__ inline void conv3x3_tile_mfma(const float* __restrict__ wt, const flo
     }
 }
 
+// conv3x3_tile for any board: thread (co, rg) walks the rows rg, rg + RG, ... eight columns at a time (the same
+// chain per output element: bias, then input channels in order, taps row by row)
+template <typename Emit>
+__device__ inline void conv3x3_tile_big(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
+                                        const float* in, int in_leaf_stride, int h, int w, int tid, Emit emit) {
+    const int co = tid % C, rg = tid / C, RG = NTHREADS / C;
+    const int WP = w + 2, chs = (h + 2) * WP;
+    const float bv = bias ? bias[co] : 0.0f;
+    for (int y = rg; y < h; y += RG)
+        for (int x0 = 0; x0 < w; x0 += 8) {
+            float acc[CNN_TILE][8];
+#pragma unroll
+            for (int l = 0; l < CNN_TILE; ++l)
+#pragma unroll
+                for (int x = 0; x < 8; ++x) acc[l][x] = bv;
+            for (int ci = 0; ci < Cin; ++ci) {
+                float wv[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wv[t] = wt[((size_t)ci * 9 + t) * C + co];
+#pragma unroll
+                for (int l = 0; l < CNN_TILE; ++l) {
+                    const float* src = in + (size_t)l * in_leaf_stride + (size_t)ci * chs;
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const float* row = src + (size_t)(y + dy) * WP + x0;
+                        float v[10];
+#pragma unroll
+                        for (int x = 0; x < 10; ++x) v[x] = x0 + x < WP ? row[x] : 0.0f;
+#pragma unroll
+                        for (int x = 0; x < 8; ++x)
+                            acc[l][x] = fmaf(wv[dy * 3 + 2], v[x + 2], fmaf(wv[dy * 3 + 1], v[x + 1], fmaf(wv[dy * 3], v[x], acc[l][x])));
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < CNN_TILE; ++l)
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+                    if (x0 + x < w) emit(l, co, y, x0 + x, acc[l][x]);
+        }
+}
+
 // scalar or matrix-core convolution by channel count (block-uniform)
 template <typename Emit>
 __device__ inline void conv3x3_any(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
                                    const float* in, int in_leaf_stride, int h, int w, int tid, Emit emit) {
     if ((C & 31) == 0 && CNN_TILE * h * w <= 32 * (NTHREADS / 64)) conv3x3_tile_mfma(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
-    else conv3x3_tile(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
+    else if (h <= 8 && w <= 8) conv3x3_tile(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
+    else conv3x3_tile_big(wt, bias, Cin, C, in, in_leaf_stride, h, w, tid, emit);
+}
+
+// heads: features at the player cells, player encoder, combiner, DeepSet heads (policy, point or pooled value);
+// `A` = the trunk's output [L][C][hw] in LDS. All threads of the block call this.
+template <int NW>
+__device__ inline void cnn_heads(const CnnDev& net, int L, int cnt, const float* A, int a_leaf, float* small,
+                                 const LeafFeat* feat, int tid, uint32_t base, ar::EvalOut* out, float* logits) {
+    const int C = net.C, hw = net.hw;
+    const int PD = net.PD, HD = net.HD;
+    float* cat = small;                    // [L][2][C+PD]
+    float* hid = cat + L * 2 * (C + PD);   // [L][2][HD]
+    float* hl = hid + L * 2 * HD;          // [L][12]
+    for (int i = tid; i < L * 2 * (C + PD); i += NTHREADS) {
+        const int l = i / (2 * (C + PD)), rem = i % (2 * (C + PD)), p = rem / (C + PD), k = rem % (C + PD);
+        const LeafFeat& f = feat[l];
+        float v;
+        if (k < C) {
+            v = A[(size_t)l * a_leaf + (size_t)k * hw + (p == 0 ? f.p1 : f.p2)];
+        } else {
+            const int o = k - C;
+            // side = [score, mud, progress]  (model.py:153-168)
+            const float s0 = f.sc[4 + p], s1 = f.sc[2 + p], s2 = f.sc[1];
+            float acc = net.pe_b[o];
+            acc = fmaf(net.pe_w[0 * PD + o], s0, acc);
+            acc = fmaf(net.pe_w[1 * PD + o], s1, acc);
+            acc = fmaf(net.pe_w[2 * PD + o], s2, acc);
+            v = fmaxf(acc, 0.0f);
+        }
+        cat[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 2 * HD; i += NTHREADS) {
+        const int l = i / (2 * HD), rem = i % (2 * HD), p = rem / HD, o = rem % HD;
+        const float* cv = cat + (size_t)(l * 2 + p) * (C + PD);
+        float acc = net.cb_b[o];
+#pragma unroll 16
+        for (int k = 0; k < C + PD; ++k) acc = fmaf(net.cb_w[(size_t)k * HD + o], cv[k], acc);
+        hid[i] = fmaxf(acc, 0.0f);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 12; i += NTHREADS) {
+        const int l = i / 12, r = i % 12, p = r / 6, o = r % 6;
+        const float* hi = hid + (size_t)(l * 2 + p) * HD;
+        const float* h0 = hid + (size_t)(l * 2) * HD;
+        const float* h1 = h0 + HD;
+        const float* wr = net.hd_w + (size_t)o * 2 * HD;
+        float acc = net.hd_b[o];
+#pragma unroll 16
+        for (int k = 0; k < HD; ++k) acc = fmaf(wr[k], hi[k], acc);
+#pragma unroll 16
+        for (int k = 0; k < HD; ++k) acc = fmaf(wr[HD + k], h0[k] + h1[k], acc);
+        hl[i] = acc;
+    }
+    __syncthreads();
+    if (net.VH > 0) {
+        const int VH = net.VH;
+        float* pool = hl + L * 12;        // [L][2C]: mean, max of the trunk's output over the board
+        float* vh = pool + L * 2 * C;     // [L][2][VH]
+        for (int i = tid; i < L * C; i += NTHREADS) {
+            const int l = i / C, c = i % C;
+            const float* a = &A[(size_t)l * a_leaf + (size_t)c * hw];
+            float s = 0.0f, mx = a[0];
+            for (int k = 0; k < hw; ++k) {
+                s += a[k];
+                mx = fmaxf(mx, a[k]);
+            }
+            pool[l * 2 * C + c] = s / (float)hw;
+            pool[l * 2 * C + C + c] = mx;
+        }
+        __syncthreads();
+        for (int i = tid; i < L * 2 * VH; i += NTHREADS) {
+            const int l = i / (2 * VH), rem = i % (2 * VH), p = rem / VH, o = rem % VH;
+            const float* hi = hid + (size_t)(l * 2 + p) * HD;
+            const float* h0 = hid + (size_t)(l * 2) * HD;
+            const float* h1 = h0 + HD;
+            const float* pl = pool + (size_t)l * 2 * C;
+            float acc = net.pv_b0[o];
+            for (int k = 0; k < 2 * C; ++k) acc = fmaf(net.pv_w0[(size_t)k * VH + o], pl[k], acc);
+            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + k) * VH + o], hi[k], acc);
+            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + HD + k) * VH + o], h0[k] + h1[k], acc);
+            vh[i] = fmaxf(acc, 0.0f);
+        }
+        __syncthreads();
+        for (int i = tid; i < L * 2; i += NTHREADS) {
+            const float* v = vh + (size_t)i * VH;
+            float acc = net.pv_b2[0];
+            for (int k = 0; k < VH; ++k) acc = fmaf(net.pv_w2[k], v[k], acc);
+            hl[(i / 2) * 12 + (i % 2) * 6 + 5] = acc;  // the value logit of leaf i / 2, player i % 2
+        }
+        __syncthreads();
+    }
+    if (tid < cnt) {
+        const float* hh = hl + tid * 12;
+        ar::EvalOut o;
+        softmax5(hh, o.p1);
+        softmax5(hh + 6, o.p2);
+        o.v1 = softplusf(hh[5]);
+        o.v2 = softplusf(hh[11]);
+        out[base + tid] = o;
+        if (logits)
+            for (int k = 0; k < 5; ++k) {
+                logits[(size_t)(base + tid) * 10 + k] = hh[k];
+                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
+            }
+    }
 }
 
 #if defined(AR_CNN_PROF)
@@ -328,90 +479,7 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
         __syncthreads();
         CNN_T(6 + bi * 4);
     }
-    // heads: features at the player cells, player encoder, combiner, DeepSet heads
-    const int PD = net.PD, HD = net.HD;
-    float* cat = small;                    // [L][2][C+PD]
-    float* hid = cat + L * 2 * (C + PD);   // [L][2][HD]
-    float* hl = hid + L * 2 * HD;          // [L][12]
-    for (int i = tid; i < L * 2 * (C + PD); i += NTHREADS) {
-        const int l = i / (2 * (C + PD)), rem = i % (2 * (C + PD)), p = rem / (C + PD), k = rem % (C + PD);
-        const LeafFeat& f = feat[l];
-        float v;
-        if (k < C) {
-            v = A[(size_t)l * a_leaf + (size_t)k * hw + (p == 0 ? f.p1 : f.p2)];
-        } else {
-            const int o = k - C;
-            // side = [score, mud, progress]  (model.py:153-168)
-            const float s0 = f.sc[4 + p], s1 = f.sc[2 + p], s2 = f.sc[1];
-            float acc = net.pe_b[o];
-            acc = fmaf(net.pe_w[0 * PD + o], s0, acc);
-            acc = fmaf(net.pe_w[1 * PD + o], s1, acc);
-            acc = fmaf(net.pe_w[2 * PD + o], s2, acc);
-            v = fmaxf(acc, 0.0f);
-        }
-        cat[i] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < L * 2 * HD; i += NTHREADS) {
-        const int l = i / (2 * HD), rem = i % (2 * HD), p = rem / HD, o = rem % HD;
-        const float* cv = cat + (size_t)(l * 2 + p) * (C + PD);
-        float acc = net.cb_b[o];
-#pragma unroll 16
-        for (int k = 0; k < C + PD; ++k) acc = fmaf(net.cb_w[(size_t)k * HD + o], cv[k], acc);
-        hid[i] = fmaxf(acc, 0.0f);
-    }
-    __syncthreads();
-    for (int i = tid; i < L * 12; i += NTHREADS) {
-        const int l = i / 12, r = i % 12, p = r / 6, o = r % 6;
-        const float* hi = hid + (size_t)(l * 2 + p) * HD;
-        const float* h0 = hid + (size_t)(l * 2) * HD;
-        const float* h1 = h0 + HD;
-        const float* wr = net.hd_w + (size_t)o * 2 * HD;
-        float acc = net.hd_b[o];
-#pragma unroll 16
-        for (int k = 0; k < HD; ++k) acc = fmaf(wr[k], hi[k], acc);
-#pragma unroll 16
-        for (int k = 0; k < HD; ++k) acc = fmaf(wr[HD + k], h0[k] + h1[k], acc);
-        hl[i] = acc;
-    }
-    __syncthreads();
-    if (net.VH > 0) {
-        const int VH = net.VH;
-        float* pool = hl + L * 12;        // [L][2C]: mean, max of the trunk's output over the board
-        float* vh = pool + L * 2 * C;     // [L][2][VH]
-        for (int i = tid; i < L * C; i += NTHREADS) {
-            const int l = i / C, c = i % C;
-            const float* a = &A[(size_t)l * a_leaf + (size_t)c * hw];
-            float s = 0.0f, mx = a[0];
-            for (int k = 0; k < hw; ++k) {
-                s += a[k];
-                mx = fmaxf(mx, a[k]);
-            }
-            pool[l * 2 * C + c] = s / (float)hw;
-            pool[l * 2 * C + C + c] = mx;
-        }
-        __syncthreads();
-        for (int i = tid; i < L * 2 * VH; i += NTHREADS) {
-            const int l = i / (2 * VH), rem = i % (2 * VH), p = rem / VH, o = rem % VH;
-            const float* hi = hid + (size_t)(l * 2 + p) * HD;
-            const float* h0 = hid + (size_t)(l * 2) * HD;
-            const float* h1 = h0 + HD;
-            const float* pl = pool + (size_t)l * 2 * C;
-            float acc = net.pv_b0[o];
-            for (int k = 0; k < 2 * C; ++k) acc = fmaf(net.pv_w0[(size_t)k * VH + o], pl[k], acc);
-            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + k) * VH + o], hi[k], acc);
-            for (int k = 0; k < HD; ++k) acc = fmaf(net.pv_w0[(size_t)(2 * C + HD + k) * VH + o], h0[k] + h1[k], acc);
-            vh[i] = fmaxf(acc, 0.0f);
-        }
-        __syncthreads();
-        for (int i = tid; i < L * 2; i += NTHREADS) {
-            const float* v = vh + (size_t)i * VH;
-            float acc = net.pv_b2[0];
-            for (int k = 0; k < VH; ++k) acc = fmaf(net.pv_w2[k], v[k], acc);
-            hl[(i / 2) * 12 + (i % 2) * 6 + 5] = acc;  // the value logit of leaf i / 2, player i % 2
-        }
-        __syncthreads();
-    }
+    cnn_heads<NW>(net, L, cnt, A, a_leaf, small, feat, tid, base, out, logits);
     CNN_T(20);
 #if defined(AR_CNN_PROF)
     if (prof && atomicCAS(&g_cnn_prof_done, 0, 1) == 0) {
@@ -423,20 +491,310 @@ __global__ void __launch_bounds__(NTHREADS) k_cnn(CnnDev net, const ar::LeafReq<
     }
     (void)tpi;
 #endif
-    if (tid < cnt) {
-        const float* hh = hl + tid * 12;
-        ar::EvalOut o;
-        softmax5(hh, o.p1);
-        softmax5(hh + 6, o.p2);
-        o.v1 = softplusf(hh[5]);
-        o.v2 = softplusf(hh[11]);
-        out[base + tid] = o;
-        if (logits)
-            for (int k = 0; k < 5; ++k) {
-                logits[(size_t)(base + tid) * 10 + k] = hh[k];
-                logits[(size_t)(base + tid) * 10 + 5 + k] = hh[6 + k];
-            }
+}
+
+// ---- PyRatCNN with the trunk state in registers (C = 32 or 64, boards up to 256 cells) ---------------------
+// The kernel above keeps three activation images per tile in LDS (trunk state A and two zero-bordered copies:
+// 108 KB at 7x7 / C = 64, one workgroup per CU, one wavefront per SIMD -- the matrix pipe idles through every
+// phase that is not a convolution: 31 % busy, profiles/r03_pmc_sq_cnn.txt). Here the trunk state x lives in the
+// registers of the wavefront that computes it, in the accumulator layout of the convolutions (row = board
+// position, column = channel), and there is ONE zero-bordered image P: a convolution's results stay in the
+// accumulators until every wavefront has finished reading P, then go over it (42 KB at 7x7 / C = 64: three
+// workgroups per CU, whose phases interleave). Rows are positions m = leaf * hw + cell of the tile's L leaves;
+// wavefront wv holds the 32-row tiles wv, wv + 4, ... (MT of them: 128 MT rows per workgroup), so a board above
+// 128 cells is one leaf over two tiles per wavefront. The pooling branch's 1x1 convolution runs on the matrix
+// cores too (its operand relu(pool_bn(x)) is laid out in P, which is free between blocks). Arithmetic, operation
+// by operation, is k_cnn's: the same k-ordered chains, the same affine / ReLU / residual order.
+static const int CNN_TILE_MAX = 8;
+
+// one 3x3 convolution for T row tiles of this wavefront: c[t][j] = bias + sum_k P-window(row, k) * w[k][co]
+template <int MT, int T>
+__device__ inline void conv3x3_rows_mfma(const float* __restrict__ wt, const float* __restrict__ bias, int Cin, int C,
+                                         const float* P, const int (&arow)[MT], const bool (&rok)[MT], int chs, int WP,
+                                         int r, int h2_, bool two, f32x16 (&c)[MT][2]) {
+    const int K = Cin * 9;
+    // (opaque copy: what follows is the same for every convolution of the trunk, and hoisted out of the loop over the
+    // blocks the per-tap offsets would sit in registers -- spilled ones -- through the whole kernel)
+    int h2 = h2_;
+    asm volatile("" : "+v"(h2));
+    int off[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        const int kl = 2 * p + h2, cl = kl >= 9 ? 1 : 0, tap = kl - 9 * cl, dy = tap / 3, dx = tap - 3 * dy;
+        off[p] = cl * chs + dy * WP + dx;
     }
+    const int n_pairs = (Cin + 1) / 2;
+    const float b0 = bias ? bias[r] : 0.0f, b1 = bias ? bias[(two ? 32 : 0) + r] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            c[t][0][v] = b0;
+            c[t][1][v] = b1;
+        }
+    // weights of two channels (18 k values, nine MFMA steps) per fetch, two register buffers in turn (the other
+    // wavefronts of the SIMD cover what one pair of distance to the L2 does not); a fetch feeds the T tiles
+    float w0a[9], w0b[9], w1a[9], w1b[9];
+    // (32-bit offsets from the uniform base, row clamped instead of a guarded load: no branch, no 64-bit address per tap)
+    const unsigned col0 = (unsigned)r, col1 = (unsigned)(r + (two ? 32 : 0));
+    auto fetch = [&](int q, float* A9, float* B9) {
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int kk = q * 18 + 2 * p + h2;
+            const unsigned row = (unsigned)(kk < K ? kk : K - 1) * (unsigned)C;
+            const float a = wt[row + col0], b = wt[row + col1];
+            A9[p] = kk < K ? a : 0.0f;
+            B9[p] = kk < K ? b : 0.0f;
+        }
+    };
+    auto multiply = [&](int q, const float* A9, const float* B9) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float* ab = P + (arow[t] + 2 * q * chs);
+            float av[9];
+#pragma unroll
+            for (int p = 0; p < 9; ++p) av[p] = rok[t] ? ab[off[p]] : 0.0f;
+#pragma unroll
+            for (int p = 0; p < 9; ++p) {
+                c[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], A9[p], c[t][0], 0, 0, 0);
+                c[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], B9[p], c[t][1], 0, 0, 0);
+            }
+        }
+    };
+    fetch(0, w0a, w0b);
+    for (int q = 0; q < n_pairs; q += 2) {
+        fetch(q + 1, w1a, w1b);
+        multiply(q, w0a, w0b);
+        if (q + 1 < n_pairs) {
+            fetch(q + 2, w0a, w0b);
+            multiply(q + 1, w1a, w1b);
+        }
+    }
+}
+
+template <int NW, int MT>
+__global__ void __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) k_cnn_mfma(CnnDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
+                                                       uint32_t n_fixed, const char* boards, size_t board_stride,
+                                                       const uint8_t* maze_pool, ar::EvalOut* out, float* logits) {
+    constexpr int ROWS = 128 * MT;
+    extern __shared__ float smem[];
+    const int L = net.L, C = net.C, h = net.height, w = net.width, hw = net.hw;
+    const int WP = w + 2, chs = (h + 2) * WP;
+    const int a_leaf = C * hw, p_leaf = C * chs, M = L * hw;
+    float* P = smem;                  // [L][C][chs] zero-bordered; between convolutions: [L][C][hw] (+ [L][G][hw])
+    float* small = P + net.p_floats;  // pooled / head vectors
+    __shared__ LeafFeat feat[CNN_TILE_MAX];
+    __shared__ int row_p[ROWS], row_u[ROWS], row_l[ROWS];  // per row: offset of its cell in P (channel 0), in [L][C][hw], leaf
+    const uint32_t n = qcount ? *qcount : n_fixed;
+    const uint32_t base = blockIdx.x * (uint32_t)L;
+    if (base >= n) return;
+    const int cnt = (int)((n - base) < (uint32_t)L ? (n - base) : (uint32_t)L);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h2 = lane >> 5;
+    const bool two = C > 32;
+    for (int m = tid; m < ROWS; m += NTHREADS) {
+        const int mm = m < M ? m : 0;
+        const int l = mm / hw, cell = mm - l * hw, y = cell / w, x = cell - y * w;
+        row_p[m] = l * p_leaf + (y + 1) * WP + (x + 1);
+        row_u[m] = l * a_leaf + cell;
+        row_l[m] = l;
+    }
+    for (int i = tid; i < L * p_leaf; i += NTHREADS) P[i] = 0.0f;
+    if (tid < L) {
+        const int l = tid < cnt ? tid : 0;
+        const ar::LeafReq<NW>& rq = q[base + l];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)rq.slot * board_stride);
+        leaf_features<NW>(rq.st, b, hw, feat[tid]);
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 5 * hw; i += NTHREADS) {
+        const int l = i / (5 * hw), rem = i % (5 * hw), c = rem / hw, cell = rem % hw;
+        const int ll = l < cnt ? l : 0;
+        const ar::LeafReq<NW>& rq = q[base + ll];
+        const ar::Board& b = *(const ar::Board*)(boards + (size_t)rq.slot * board_stride);
+        float v;
+        if (c < 4) {
+            const uint8_t cst = maze_pool[b.maze_off + (uint32_t)cell * 4u + (uint32_t)c];
+            v = cst ? (float)cst / 10.0f : -1.0f;
+        } else {
+            v = ar::st_has_cheese(rq.st, cell) ? 1.0f : 0.0f;
+        }
+        P[(size_t)l * p_leaf + (size_t)c * chs + (size_t)(cell / w + 1) * WP + (cell % w + 1)] = v;
+    }
+    // this lane's operand rows (window origin in P) and how many of the wavefront's tiles hold rows at all
+    int arow[MT], urow[MT];
+    bool rok[MT];
+    int n_on = 0;  // wave-uniform
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        rok[t] = (wave + 4 * t) * 32 + r < M;
+        if ((wave + 4 * t) * 32 < M) n_on = t + 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = (wave + 4 * t) * 32 + r;
+        arow[t] = row_p[rok[t] ? m : 0] - WP - 1;
+        urow[t] = row_u[rok[t] ? m : 0];
+    }
+    auto conv = [&](const float* wt, const float* bias, int Cin, f32x16(&c)[MT][2]) {
+        if (MT == 2 && n_on == 2) conv3x3_rows_mfma<MT, MT>(wt, bias, Cin, C, P, arow, rok, chs, WP, r, h2, two, c);
+        else if (n_on >= 1) conv3x3_rows_mfma<MT, 1>(wt, bias, Cin, C, P, arow, rok, chs, WP, r, h2, two, c);
+    };
+    // result rows of this lane: tile t, register v -> row mo
+    auto row_of = [&](int t, int v) -> int { return (wave + 4 * t) * 32 + (v & 3) + 8 * (v >> 2) + 4 * h2; };
+    f32x16 xs[MT][2], acc[MT][2];
+    // stem: conv(5 -> C) + folded stem_bn + ReLU
+    conv(net.stem_w, net.stem_b, 5, acc);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            xs[t][0][v] = fmaxf(acc[t][0][v], 0.0f);
+            xs[t][1][v] = fmaxf(acc[t][1][v], 0.0f);
+        }
+    __syncthreads();  // every wavefront is done reading P
+    for (int bi = 0; bi < net.n_blocks; ++bi) {
+        const CnnBlockDev& blk = net.blk[bi];
+        float* pout = small;  // [L][C] pooled-branch output (gpool blocks)
+        if (blk.gpool) {
+            const int G = blk.gpool;
+            float* U = P;                         // [L][C][hw] relu(pool_bn(x))
+            float* pc = P + (size_t)L * a_leaf;   // [L][G][hw]
+            {
+                const float a0 = blk.pbn_a[r], c0 = blk.pbn_b[r], a1 = blk.pbn_a[two ? r + 32 : r], c1 = blk.pbn_b[two ? r + 32 : r];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int mo = row_of(t, v);
+                        if (t < n_on && mo < M) {
+                            const int u = row_u[mo];
+                            U[u + r * hw] = fmaxf(fmaf(a0, xs[t][0][v], c0), 0.0f);
+                            if (two) U[u + (r + 32) * hw] = fmaxf(fmaf(a1, xs[t][1][v], c1), 0.0f);
+                        }
+                    }
+            }
+            __syncthreads();
+            // 1x1 convolution C -> G on the matrix cores: pc[m][g] = sum_c U[m][c] * wp[c][g] (k = c, from 0)
+            {
+                const bool g0 = r < G, g1 = r + 32 < G, wide = G > 32;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[t][0][v] = acc[t][1][v] = 0.0f;
+                if (n_on >= 1) {
+#pragma unroll 4
+                    for (int k = 0; k < C; k += 2) {
+                        const float b0 = g0 ? blk.wp[(size_t)(k + h2) * G + r] : 0.0f;
+                        const float b1 = g1 ? blk.wp[(size_t)(k + h2) * G + r + 32] : 0.0f;
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            if (t < n_on) {
+                                const float a = rok[t] ? U[urow[t] + (k + h2) * hw] : 0.0f;
+                                acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[t][0], 0, 0, 0);
+                                if (wide) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[t][1], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int mo = row_of(t, v);
+                        if (t < n_on && mo < M) {
+                            const int l = row_l[mo], cell = row_u[mo] - l * a_leaf;
+                            if (g0) pc[(size_t)l * G * hw + (size_t)r * hw + cell] = acc[t][0][v];
+                            if (g1) pc[(size_t)l * G * hw + (size_t)(r + 32) * hw + cell] = acc[t][1][v];
+                        }
+                    }
+            }
+            __syncthreads();
+            float* pcat = small + L * C;  // [L][2G]
+            for (int i = tid; i < L * G; i += NTHREADS) {
+                const int l = i / G, g = i % G;
+                const float* p = pc + (size_t)l * G * hw + (size_t)g * hw;
+                float s = 0.0f, mx = p[0];
+                for (int c2 = 0; c2 < hw; ++c2) {
+                    s += p[c2];
+                    mx = fmaxf(mx, p[c2]);
+                }
+                pcat[l * 2 * G + g] = s / (float)hw;
+                pcat[l * 2 * G + G + g] = mx;
+            }
+            __syncthreads();
+            for (int i = tid; i < L * C; i += NTHREADS) {
+                const int l = i / C, c = i % C;
+                float a = blk.bl[c];
+#pragma unroll 16
+                for (int k = 0; k < 2 * G; ++k) a = fmaf(blk.wl[(size_t)k * C + c], pcat[l * 2 * G + k], a);
+                pout[l * C + c] = a;
+            }
+            for (int i = tid; i < L * p_leaf; i += NTHREADS) P[i] = 0.0f;  // the zero borders again
+            __syncthreads();
+        }
+        // P = pad(relu(bn1(x)))
+        {
+            const float a0 = blk.bn1_a[r], c0 = blk.bn1_b[r], a1 = blk.bn1_a[two ? r + 32 : r], c1 = blk.bn1_b[two ? r + 32 : r];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int mo = row_of(t, v);
+                    if (t < n_on && mo < M) {
+                        const int p = row_p[mo];
+                        P[p + r * chs] = fmaxf(fmaf(a0, xs[t][0][v], c0), 0.0f);
+                        if (two) P[p + (r + 32) * chs] = fmaxf(fmaf(a1, xs[t][1][v], c1), 0.0f);
+                    }
+                }
+        }
+        __syncthreads();
+        conv(blk.w1, blk.b1, C, acc);  // bn2 folded
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int mo = row_of(t, v);
+                if (t < n_on && mo < M) {
+                    const int p = row_p[mo];
+                    P[p + r * chs] = fmaxf(acc[t][0][v], 0.0f);
+                    if (two) P[p + (r + 32) * chs] = fmaxf(acc[t][1][v], 0.0f);
+                }
+            }
+        __syncthreads();
+        conv(blk.w2, nullptr, C, acc);
+        // x = conv2 [+ pooled] + x
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                if (blk.gpool) {
+                    const int mo = row_of(t, v), l = row_l[mo < M ? mo : 0];
+                    xs[t][0][v] = acc[t][0][v] + pout[l * C + r] + xs[t][0][v];
+                    xs[t][1][v] = acc[t][1][v] + pout[l * C + (two ? r + 32 : r)] + xs[t][1][v];
+                } else {
+                    xs[t][0][v] = acc[t][0][v] + xs[t][0][v];
+                    xs[t][1][v] = acc[t][1][v] + xs[t][1][v];
+                }
+            }
+        __syncthreads();
+    }
+    // the trunk's output as [L][C][hw] for the heads
+    float* A = P;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int mo = row_of(t, v);
+            if (t < n_on && mo < M) {
+                const int u = row_u[mo];
+                A[u + r * hw] = xs[t][0][v];
+                if (two) A[u + (r + 32) * hw] = xs[t][1][v];
+            }
+        }
+    __syncthreads();
+    cnn_heads<NW>(net, L, cnt, A, a_leaf, small, feat, tid, base, out, logits);
 }
 
 // ---- host: blob -> device weights ---------------------------------------------------------------

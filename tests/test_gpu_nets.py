@@ -47,12 +47,15 @@ def test_device_encoder_golden(path):
 
 @pytest.mark.parametrize("name", ["mlp_5x5_h32", "mlp_7x7_h256", "symmetric_5x5_h32", "symmetric_7x7_h256",
                                   "cnn_res_5x5_c16", "cnn_gpool_7x5_c16", "cnn_gpool_7x7_c64",
-                                  "cnn_pooled_7x5_c16", "cnn_pooled_7x7_c32"])  # (pooled: value_head.type "pooled")
+                                  "cnn_pooled_7x5_c16", "cnn_pooled_7x7_c32",  # (pooled: value_head.type "pooled")
+                                  # boards above 8x8: matrix-core kernel with two row tiles per wavefront (c32, c64),
+                                  # the FMA kernel's row / column loops (c16)
+                                  "cnn_gpool_15x11_c32", "cnn_res_15x11_c64", "cnn_gpool_9x10_c16"])
 def test_device_net_matches_reference_outputs(name):
     from alpharat_amd.nets import Net, encode
 
     gold = np.load(GOLD / "nets" / f"{name}.npz")
-    w, h = (5, 5) if "5x5" in name else (7, 5) if "7x5" in name else (7, 7)
+    w, h = (int(v) for v in next(t for t in name.split("_") if t[0].isdigit()).split("x"))
     games = [_game_from_obs(o, w, h) for o in gold["obs"]]
     np.testing.assert_allclose(encode(games), gold["obs"], atol=1e-6, rtol=0)
     out = Net(GOLD / "nets" / f"{name}.arnet").evaluate(games)
@@ -78,6 +81,44 @@ def test_symmetric_on_matrix_cores_gives_the_bits_of_the_fma_loops(name, w, h, m
     for k in a:
         assert a[k].tobytes() == c[k].tobytes(), k
         assert a[k].tobytes() == b[k][::-1].tobytes(), k
+
+
+@pytest.mark.parametrize("name,w,h", [("cnn_gpool_7x7_c64", 7, 7), ("cnn_pooled_7x7_c32", 7, 7)])
+def test_cnn_with_trunk_in_registers_gives_the_bits_of_the_three_image_kernel(name, w, h, monkeypatch):
+    """k_cnn_mfma (trunk state in registers, one LDS image, pooling branch on the matrix cores) runs the same k-ordered
+    chains as k_cnn (AR_CNN_LDS=1, chosen when the weights are loaded), whatever row a position lands in: 35 positions
+    (ragged last tile), bit for bit, and again in another order."""
+    from alpharat_amd.nets import Net
+
+    gold = np.load(GOLD / "nets" / f"{name}.npz")
+    games = [_game_from_obs(o, w, h) for o in gold["obs"]]
+    games = (games * 2)[:35]
+    net = Net(GOLD / "nets" / f"{name}.arnet")
+    a = net.evaluate(games)
+    b = net.evaluate(games[::-1])
+    monkeypatch.setenv("AR_CNN_LDS", "1")
+    c = Net(GOLD / "nets" / f"{name}.arnet").evaluate(games)
+    for k in a:
+        assert a[k].tobytes() == c[k].tobytes(), k
+        assert a[k].tobytes() == b[k][::-1].tobytes(), k
+
+
+def test_mlp_first_layer_variants_give_the_same_bits(monkeypatch):
+    """k_mlp_mfma's first layer: the p1 / p2 weight rows summed into the start of the chain and only cheese and scalars on
+    the matrix cores (default), the whole non-maze observation as a product with the operand staged in LDS (AR_MLP_FL=0)
+    or formed in registers (AR_MLP_FL=1): the same k-ordered chain, the same bits; 150 positions."""
+    from alpharat_amd.nets import Net
+
+    gold = np.load(GOLD / "nets" / "mlp_7x7_h256.npz")
+    games = [_game_from_obs(o, 7, 7) for o in gold["obs"]]
+    games = (games * 7)[:150]
+    net = Net(GOLD / "nets" / "mlp_7x7_h256.arnet")
+    a = net.evaluate(games)
+    for fl in ("0", "1"):
+        monkeypatch.setenv("AR_MLP_FL", fl)
+        c = net.evaluate(games)
+        for k in a:
+            assert a[k].tobytes() == c[k].tobytes(), (fl, k)
 
 
 def test_search_with_device_net_close_to_oracle_net():

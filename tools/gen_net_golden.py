@@ -154,6 +154,15 @@ def main() -> int:
             hidden_dim=16)),
         ("cnn_pooled_7x7_c32", "cnn", (7, 7), dict(trunk=dict(channels=32, blocks=[dict(type="res"), dict(type="res")]),
                                                    value_head=dict(type="pooled"), player_dim=16, hidden_dim=32)),
+        # boards above 8x8 (configs/game/15x11_open_asymmetric.yaml; cnn/model.py:167-230 is size-agnostic): one leaf over
+        # two row tiles per wavefront on the matrix cores, and the FMA path's row / column loops
+        ("cnn_gpool_15x11_c32", "cnn", (15, 11), dict(trunk=dict(channels=32, blocks=[
+            dict(type="res"), dict(type="gpool", gpool_channels=16)]), value_head=dict(type="pooled"), player_dim=16,
+            hidden_dim=32)),
+        ("cnn_gpool_9x10_c16", "cnn", (9, 10), dict(trunk=dict(channels=16, blocks=[
+            dict(type="gpool", gpool_channels=8), dict(type="res")]), player_dim=8, hidden_dim=16)),
+        ("cnn_res_15x11_c64", "cnn", (15, 11), dict(trunk=dict(channels=64, blocks=[dict(type="res")]), player_dim=16,
+                                                  hidden_dim=32)),
     ]
     only = set(sys.argv[1:])  # (names on the command line: regenerate just those; seeds depend on the case's index only)
     for idx, (name, arch, (w, h), kw) in enumerate(cases):
