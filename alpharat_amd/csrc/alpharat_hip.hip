@@ -480,13 +480,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WP
 
 // The gather as a work queue over tree levels (dev_gatherw.h): a wavefront serves G game contexts at once, every node
 // a pick reaches is an item in the wavefront's LDS ring, and each pass the 64 lanes take the next 64 items -- of
-// whichever games they are. The grid is persistent: context c of wavefront b walks the games first + (j * gridDim.x + b) * G
-// + c, j = 0, 1, ... one after the other (consecutive slots per wavefront and turn), so the lanes stay busy until the
-// launch runs out of games. Leaves are left in the games' scratch (k_pack_leaves appends them to the evaluator queue).
+// whichever games they are. The grid is persistent: context c of wavefront b walks game c of the sets (of G consecutive
+// slots) j * gridDim.x + b, j = 0, 1, ... one after the other, so the lanes stay busy until the launch runs out of games.
+// With a pass limit the sets of turn j >= 1 only get the passes their wavefront's first set leaves over, so the numbering of
+// the sets is rotated from launch to launch (`rot`: set v of this launch is set (v + rot) mod n_sets; the host advances rot
+// by n_sets - gridDim.x per launch, the width of the second turn): every game waits its share of the launches instead of
+// the same eighth of the games waiting in all of them. Which wavefront walks a game never changes what its walk does.
+// Leaves are left in the games' scratch (k_pack_leaves appends them to the evaluator queue).
 // Ring item: context (bits 0..6), BEGIN flag (bit 7: the context wants a game), visit slot, siblings behind it.
 template <int NW, int G, int R>
 __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slots, SearchCfg cfg, Bases B, uint32_t first,
-                                                uint32_t phase, uint32_t accept_ready, uint32_t pass_limit) {
+                                                uint32_t phase, uint32_t accept_ready, uint32_t pass_limit, uint32_t rot) {
     static_assert((G & (G - 1)) == 0 && G <= 64, "the ring is a power of two; a context number fits a ring item");
     static_assert(sizeof(GwRec<NW>) == (sizeof(State<NW>) + 16 + 7) / 8 * 8, "slot_layout.h sizes the spill area");
     typedef GwShared<NW, G, R> Sh;
@@ -549,10 +553,18 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
         ln.g = g;
         // ---- phase 1
         uint32_t slot_i = NIL;
+        bool skip = false;  // a context beyond the end of a ragged last set: nothing to walk this turn, but the next may have
         if (begin && guard < pass_limit) {  // (past the limit no game is begun: its turn comes with the next launch)
             const uint32_t turn = sh.game[g].next_game;
             sh.game[g].next_game = turn + 1u;
-            slot_i = first + (turn * gridDim.x + blockIdx.x) * (uint32_t)G + g;
+            const uint32_t n_sets = (n_slots - first + (uint32_t)G - 1u) / (uint32_t)G;
+            const uint32_t v = turn * gridDim.x + blockIdx.x;
+            if (v < n_sets) {
+                uint32_t set = v + rot;
+                if (set >= n_sets) set -= n_sets;
+                slot_i = first + set * (uint32_t)G + g;
+                skip = slot_i >= n_slots;
+            }
         }
         if (ln.active) gw_fetch<NW, R>(ln, item, sh.game, &sh.rec[0][0], &sh.stub[0][0], &sh.stub_node[0][0], m);
         // ---- phase 2
@@ -560,7 +572,7 @@ __global__ void __launch_bounds__(64) k_gatherw(Slot<NW>* slots, uint32_t n_slot
         bool started = false, retire = false;
         if (begin) {
             if (slot_i >= n_slots) {
-                retire = true;
+                retire = !skip;
             } else {
                 Slot<NW>& S = slots[slot_i];
                 const uint32_t st = S.status;
@@ -1617,8 +1629,9 @@ struct Engine {
     // passes one launch may run; gathers that are not complete then are parked between two picks and go on in the next
     // launch. A game needs 50 passes in the median, 110 at the 90th and 160 at the 99th percentile, a few need 300+
     // (profiles/r03_gw_stats.txt): without a limit every launch lasts as long as its slowest game. Measured at 131072
-    // resident games: 64 / 80 / 96 / 128 / 192 passes -> 638 / 646 / 643 / 615 / 598 M simulations/s.
-    uint32_t gatherw_passes = 96;
+    // resident games: 64 / 80 / 96 / 128 / 192 passes -> 638 / 646 / 643 / 615 / 598 M simulations/s; with the faster
+    // evaluator and the late tree reuse of the round's end 64 / 72 / 80 -> 742 / 736 / 729 M (profiles/r03_sweeps.md).
+    uint32_t gatherw_passes = 64;
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     size_t region_bytes = 0;
     uint32_t region_low_mb = 0xFFFFFFFFu;  // least the region had left: MB never carved + MB in free blocks
@@ -1863,7 +1876,7 @@ struct Engine {
     bool merge_per_group = false;
     bool stagger_gathers = false;
     int cu_split = 0;  // 1: groups on the low / high half of the CU mask bits, 2: even / odd bits
-    bool adv_late = false;
+    bool adv_late = true;   // AR_ADV_LATE=0: the tree reuse beside the group's next tree walk, as before
     std::vector<Group> groups;
     int make_groups(uint32_t n) {
         if (n < 1) n = 1;
@@ -1944,8 +1957,10 @@ struct Engine {
             constexpr int GWG = NW == 1 ? 32 : 16;
             uint32_t waves = (n + 3) / 4;
             if (waves > gatherw_waves) waves = gatherw_waves;
+            const uint32_t n_sets = (n + GWG - 1) / GWG, second_turn = n_sets > waves ? n_sets - waves : 0u;
+            const uint32_t rot = second_turn ? (uint32_t)((g.step * (uint64_t)second_turn) % n_sets) : 0u;
             hipLaunchKernelGGL((k_gatherw<NW, GWG, 4>), dim3(waves), dim3(64), (size_t)bases().maze_stage, g.stream, slots.p, g.end, cfg,
-                               bases(), g.first, phase, ready, gatherw_passes);
+                               bases(), g.first, phase, ready, gatherw_passes, rot);
         } else if (gather8 && gather8_wpe == 3)
             hipLaunchKernelGGL((k_gather8<NW, 3>), dim3((n + 7) / 8), dim3(64), 0, g.stream, slots.p, g.end, cfg, bases(), q,
                                qc, g.first, phase, ready);
@@ -1999,7 +2014,7 @@ struct Engine {
         // blocks the group's trees left at the last step go back on the free stacks (nothing reads them any more, and
         // this stream is the only one that pops or returns in the group's zones)
         if (side && adv_late) {
-            // (AR_ADV_LATE=1) The tree reuse of this step is launched behind the NEXT gather of the group (launch_late_advance),
+            // The tree reuse of this step is launched behind the NEXT gather of the group (launch_late_advance),
             // so that it runs beside the evaluator, which leaves the memory system alone, instead of beside the tree walk,
             // which it slows down by a fifth (profiles/r03_sweeps.md: the gather launch with and without k_advance beside it)
             HIP_TRY(hipEventRecord(g.backed_up, g.stream));

@@ -889,8 +889,9 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric(NetDev net, const ar::Le
 // ~49 KB of L2 reads per leaf. Here a block's rows are (player, leaf) pairs -- 64 rows for 32 leaves -- so the player
 // encoder, both trunk layers and the heads run once over two row tiles and the trunk weights are read once per block:
 // half the L2 traffic, four independent accumulator chains per wavefront. Per output the k-ordered chain is unchanged
-// (same bits as k_symmetric_mfma and the FMA loops). LDS: shared encoding [32][ld] + one [64][ld] buffer that holds
-// the player encodings, then trunk 1, then h (100 KB at H = 256: one block per CU).
+// (same bits as the FMA loops). LDS: ONE [64][ld] buffer (67 KB at H = 256: two blocks per CU) that holds in turn the
+// shared encoder's operand, the shared encoding (rows 0..31, read by the first half of trunk 1), the player encodings
+// (read by the second half), trunk 1 and h; results wait in the accumulators until the buffer's readers are done.
 template <int NW>
 __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
                                                               uint32_t n_fixed, const char* boards, size_t board_stride,
@@ -898,8 +899,8 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const 
     constexpr int L = 32;
     extern __shared__ float smem[];
     const int H = net.H, hw = net.hw, ld = H + 4;
-    float* bufA = smem;                    // shared encoding [L][ld]
-    float* bufB = smem + (size_t)L * ld;   // [2 L][ld]: row = player * L + leaf
+    float* bufB = smem;  // [2 L][ld]: in turn the shared encoder's operand and output (rows 0..31), the player encodings,
+                         // trunk 1 and h (row = player * L + leaf)
     __shared__ LeafFeat feat[L];
     __shared__ unsigned long long cheese[L][4];
     __shared__ float hl[L * 12];
@@ -920,9 +921,6 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const 
     const int n0 = wave * 64;
     const bool has = n0 < H, two = n0 + 32 < H;  // wave-uniform; H <= 64 * waves
     const int c1 = two ? 32 : 0;
-    const LeafFeat f = feat[r];  // this lane's leaf (row r of either row tile)
-    unsigned long long ch[NW];
-    for (int w = 0; w < NW; ++w) ch[w] = cheese[r][w];
     f32x16 c[2][2];  // [row tile = player][column tile]
     auto store_relu2 = [&]() {
 #pragma unroll
@@ -944,9 +942,19 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const 
                 c[t][1][v] = b1;
             }
     };
+    // ---- shared encoder (one row tile: the 32 leaves): operand x = [cheese | progress] staged at the head of rows
+    // 0..31 (the k-loop then reads it like any activation: one LDS read per MFMA pair, no per-step selects or branches)
+    const int Ks = hw + 1, Kse = (Ks + 1) & ~1;
+    {
+        constexpr int TPL = NTHREADS / L;
+        const int l = tid / TPL;
+        float* x = bufB + (size_t)l * ld;
+        for (int kk = tid % TPL; kk < Kse; kk += TPL)
+            x[kk] = kk < hw ? ((cheese[l][kk >> 6] >> (kk & 63)) & 1ULL ? 1.0f : 0.0f) : kk == hw ? feat[l].sc[1] : 0.0f;
+    }
+    __syncthreads();
+    f32x16 cs[1][2];
     if (has) {
-        // ---- shared encoder (one row tile: the 32 leaves) -> A
-        f32x16 cs[1][2];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
@@ -954,41 +962,54 @@ __global__ void __launch_bounds__(NTHREADS) k_symmetric_mfma2(NetDev net, const 
             cs[0][0][v] = cm[0];
             cs[0][1][v] = cm[c1];
         }
-        auto x_sh = [&](int k, int) -> float {
-            const int kk = k + h;
-            if (kk < hw) {
-                unsigned long long word = ch[0];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) word = (kk >> 6) == w ? ch[w] : word;
-                return (word >> (kk & 63)) & 1ULL ? 1.0f : 0.0f;
-            }
-            return kk == hw ? f.sc[1] : 0.0f;
-        };
-        mfma_pass<1, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, hw + 1, H, h, x_sh, cs);
+        const float* xp = bufB + (size_t)r * ld + h;
+        auto x_sh = [&](int k, int) -> float { return xp[k]; };
+        mfma_pass<1, 8>(net.w1t + (size_t)(4 * hw + h) * H + n0 + r, two, Ks, H, h, x_sh, cs);
+    }
+    __syncthreads();  // every wavefront is done reading x
+    if (has) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-            bufA[(size_t)i * ld + n0 + r] = fmaxf(cs[0][0][v], 0.0f);
-            if (two) bufA[(size_t)i * ld + n0 + 32 + r] = fmaxf(cs[0][1][v], 0.0f);
+            bufB[(size_t)i * ld + n0 + r] = fmaxf(cs[0][0][v], 0.0f);
+            if (two) bufB[(size_t)i * ld + n0 + 32 + r] = fmaxf(cs[0][1][v], 0.0f);
         }
-        // ---- player encoder, both players (row tile t = player) -> B
-        init_bias2(net.bp);
-        auto x_pe = [&](int k, int t) -> float {
-            const int kk = k + h;
-            const int pos = t == 0 ? f.p1 : f.p2;
-            if (kk < hw) return kk == pos ? 1.0f : 0.0f;
-            return kk == hw ? f.sc[2 + t] : kk == hw + 1 ? f.sc[4 + t] : 0.0f;
-        };
-        mfma_pass<2, 8>(net.wpt + (size_t)h * H + n0 + r, two, hw + 2, H, h, x_pe, c);
-        store_relu2();
     }
     __syncthreads();
     if (has) {
-        // ---- trunk 1: k over the shared encoding (row r of A for both players), then over the player encodings
+        // ---- trunk 1, first half: k over the shared encoding (row r of rows 0..31 for both players)
         init_bias2(net.b2);
-        const float* ap = bufA + (size_t)r * ld + h;
+        const float* ap = bufB + (size_t)r * ld + h;
         auto a_sh = [&](int k, int) -> float { return ap[k]; };
         mfma_pass<2, 8>(net.w2t + (size_t)h * H + n0 + r, two, H, H, h, a_sh, c);
+    }
+    __syncthreads();  // the shared encoding has been read: the buffer takes the player encodings
+    {
+        // ---- player encoder, both players (row = player * L + leaf). Its input is one-hot over the player's cell plus
+        // two scalars, so the k-ordered chain bias, fma(x_k, w_k, .) is: bias + row of the cell (the zero products add
+        // nothing, the 1 adds the row), then the two scaled rows -- three weight rows per output instead of hw + 2 steps
+        // on the matrix cores, the same bits. 16 bytes of columns per item.
+        const int H4 = H >> 2;
+        const float4* bias4 = (const float4*)net.bp;
+        const float4* wm = (const float4*)(net.wpt + (size_t)hw * H);
+        const float4* ws = (const float4*)(net.wpt + (size_t)(hw + 1) * H);
+        for (int item = tid; item < 2 * L * H4; item += NTHREADS) {
+            const int row = item / H4, c4 = item - row * H4, t = row / L, l = row - t * L;
+            const LeafFeat& f = feat[l];
+            const float4 wc = ((const float4*)(net.wpt + (size_t)(t == 0 ? f.p1 : f.p2) * H))[c4];
+            const float4 b = bias4[c4], m = wm[c4], s4 = ws[c4];
+            const float mud = f.sc[2 + t], score = f.sc[4 + t];
+            float4 o;
+            o.x = fmaxf(fmaf(score, s4.x, fmaf(mud, m.x, b.x + wc.x)), 0.0f);
+            o.y = fmaxf(fmaf(score, s4.y, fmaf(mud, m.y, b.y + wc.y)), 0.0f);
+            o.z = fmaxf(fmaf(score, s4.z, fmaf(mud, m.z, b.z + wc.z)), 0.0f);
+            o.w = fmaxf(fmaf(score, s4.w, fmaf(mud, m.w, b.w + wc.w)), 0.0f);
+            *(float4*)(bufB + (size_t)row * ld + 4 * c4) = o;
+        }
+    }
+    __syncthreads();
+    if (has) {
+        // ---- trunk 1, second half: k over the player encodings
         const float* bp = bufB + (size_t)r * ld + h;
         auto a_pe = [&](int k, int t) -> float { return bp[(size_t)(32 * t) * ld + k]; };
         mfma_pass<2, 8>(net.w2t + (size_t)(H + h) * H + n0 + r, two, H, H, h, a_pe, c);
@@ -1402,7 +1423,7 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
         hipLaunchKernelGGL(k_mlp<NW>, dim3(blocks), dim3(NTHREADS), net->smem, stream, net->dev, q, qcount, n_max, boards,
                            board_stride, out, logits);
     } else if (sym_mfma) {
-        const size_t smem = (size_t)3 * 32 * (net->dev.H + 4) * 4;
+        const size_t smem = (size_t)2 * 32 * (net->dev.H + 4) * 4;
         if (smem > 48 * 1024 && hipFuncSetAttribute((const void*)k_symmetric_mfma2<NW>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return nets_fail(AR_E_DEVICE, "cannot reserve LDS for the SymmetricMLP kernel");
