@@ -1630,7 +1630,8 @@ struct Engine {
     // launch. A game needs 50 passes in the median, 110 at the 90th and 160 at the 99th percentile, a few need 300+
     // (profiles/r03_gw_stats.txt): without a limit every launch lasts as long as its slowest game. Measured at 131072
     // resident games: 64 / 80 / 96 / 128 / 192 passes -> 638 / 646 / 643 / 615 / 598 M simulations/s; with the faster
-    // evaluator and the late tree reuse of the round's end 64 / 72 / 80 -> 742 / 736 / 729 M (profiles/r03_sweeps.md).
+    // evaluator and the late tree reuse of the round's end, over windows of five generations of games: 32 / 48 / 64 / 96 ->
+    // 726 / 732 / 730 / 721 M (profiles/r03_sweeps.md; shorter windows sample one phase of the games and mislead).
     uint32_t gatherw_passes = 64;
     uint32_t gather_rounds = 0xFFFFFFFFu;  // rounds one k_gather launch may run per lane (self-play sets a limit)
     size_t region_bytes = 0;
