@@ -1369,7 +1369,9 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
     if (n_max == 0) return AR_OK;
     const bool mlp_mfma = net->dev.arch == ARCH_MLP && mlp_all_mfma(net->dev.H);
     static const int mlp_mt = getenv("AR_MLP_MT") && atoi(getenv("AR_MLP_MT")) == 1 ? 1 : MLP_MFMA_MT;  // tuning knob
-    const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA");
+    // (k_symmetric_mfma2 stages the shared encoder's operand, hw + 1 values, at the head of a row of its buffer)
+    const bool sym_mfma = net->dev.arch == ARCH_SYMMETRIC && symmetric_mfma_ok(net->dev.H) && !getenv("AR_SYM_FMA") &&
+                          ((net->dev.hw + 2) & ~1) <= net->dev.H + 4;
     const int tile = mlp_mfma ? 32 * mlp_mt : net->dev.arch == ARCH_MLP ? TILE_MLP : net->dev.arch == ARCH_CNN ? net->cnn.L
                                                                         : sym_mfma ? 32 : TILE_SYM;
     const uint32_t blocks = (n_max + tile - 1) / tile;
@@ -1395,7 +1397,9 @@ static int net_launch(ArNet* net, const ar::LeafReq<NW>* q, const uint32_t* qcou
         // 0 needs the whole observation's non-maze part in a row of `act`
         int fl = getenv("AR_MLP_FL") ? atoi(getenv("AR_MLP_FL")) : 2;
         const int K1e = (3 * net->dev.hw + 6 + 1) & ~1;
+        const int K2e = (net->dev.hw + 6 + 1) & ~1;
         if (fl < 0 || fl > 2) fl = 2;
+        if (fl == 2 && K2e > net->dev.H + 4) fl = 1;  // (the staged operand is a row of `act`: narrow hidden layers on big boards)
         if (fl == 0 && K1e > net->dev.H + 4) fl = 1;
         const void* fns[2][3] = {{(const void*)k_mlp_mfma<NW, 1, 0>, (const void*)k_mlp_mfma<NW, 1, 1>, (const void*)k_mlp_mfma<NW, 1, 2>},
                                  {(const void*)k_mlp_mfma<NW, 2, 0>, (const void*)k_mlp_mfma<NW, 2, 1>, (const void*)k_mlp_mfma<NW, 2, 2>}};

@@ -191,9 +191,10 @@ def test_selfplay_records_do_not_depend_on_scheduling(monkeypatch):
                     assert val == other[i][key], (env, i, key)
 
 
-@pytest.mark.parametrize("hidden", [48, 64, 96, 320], ids=lambda h: f"h{h}")
+@pytest.mark.parametrize("hidden", [32, 48, 64, 96, 320], ids=lambda h: f"h{h}")
 def test_device_mlp_other_hidden_widths_match_the_oracle_net(hidden, tmp_path):
-    """Hidden widths the golden vectors do not cover take other kernel paths (48: scalar tile loops;
+    """Hidden widths the golden vectors do not cover take other kernel paths (32: matrix-core kernel whose activation rows
+    are too short for the staged first-layer operand at 7x7 -- it is formed in registers; 48: scalar tile loops;
     64 / 96: matrix-core kernel with idle or single-tile wavefronts; 320: matrix-core second layer with
     two activation buffers). Seeded random weights, 70 random positions (more than one 64-leaf tile),
     compared with the oracle's forward pass of the same blob on the device's own observations."""
