@@ -559,8 +559,10 @@ __device__ inline void mfma_pass(const float* bp0, bool two, int K, int H, int h
     }
 }
 
-// (128 vector + 64 accumulator registers = 192: two wavefronts of this kernel and one of k_advance -- 128 -- fill a SIMD's
-// 512; at 196 a tree-reuse wavefront on a SIMD kept the CU's second evaluator workgroup out for as long as it ran)
+// (amdgpu_num_vgpr: with the limit the compiler keeps the accumulators in ordinary vector registers and needs 148 in all,
+// without it 130 + 64 accumulator registers = 196 (200 allocated): two such wavefronts leave a SIMD 112 of its 512
+// registers, and a tree-reuse wavefront (k_advance: 128) on a SIMD then kept the CU's second evaluator workgroup out for
+// as long as it ran. A/B of the two builds: +1.3 % simulations/s.)
 template <int NW, int MT, int FL>
 __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_vgpr(128))) k_mlp_mfma(NetDev net, const ar::LeafReq<NW>* q, const uint32_t* qcount,
                                                        uint32_t n_fixed, const char* boards, size_t board_stride,
@@ -648,9 +650,7 @@ __global__ void __launch_bounds__(NTHREADS) __attribute__((amdgpu_num_vgpr(128))
                     c[t][0][v] = act[(size_t)i * ld + n0 + r];
                     c[t][1][v] = act[(size_t)i * ld + n0 + (two ? 32 : 0) + r];
                 }
-                // (one row tile's 32 reads at a time: all 64 in flight at once cost 64 more registers than the kernel
-                // needs anywhere else, and with them the room for a tree-reuse wavefront beside two of the evaluator's)
-                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);  // (one row tile's 32 reads at a time)
             }
         }
         __syncthreads();  // the starts are in registers: `act` now takes the operand
