@@ -1234,6 +1234,13 @@ static int net_build(const arnet::Blob& b, ArNet* net) {
             c.L = 128 * c.MT / c.hw;
             if (c.L > CNN_TILE_MAX) c.L = CNN_TILE_MAX;
             while (c.L > 1 && (size_t)c.L * c.C * chs * 4 > 64 * 1024) c.L -= 1;
+            if (const char* e = getenv("AR_CNN_L")) {  // tuning knob: leaves per workgroup (more rows per tile, fewer workgroups per CU)
+                const int want = atoi(e);
+                if (want >= 1 && want <= CNN_TILE_MAX && want * c.hw <= 256) {
+                    c.L = want;
+                    c.MT = want * c.hw > 128 ? 2 : 1;
+                }
+            }
         } else if (c.C % 32 == 0 && (c.width > 8 || c.height > 8)) {
             return nets_fail(AR_E_BACKEND, "AR_CNN_LDS: the three-image CNN kernel handles 32 / 64 channels on boards up to 8x8");
         }
